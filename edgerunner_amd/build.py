@@ -1,0 +1,44 @@
+"""Builds the HIP extension in-tree: ``edgerunner_amd/libedgerunner_hip.so`` for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting .so travels to the GPU box with the snapshot (it is git-ignored, not
+gpurun-ignored).  ``python -m edgerunner_amd.build`` or ``__graft_entry__.build()``.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG, "csrc", "er_api.hip")
+LIB = os.path.join(PKG, "libedgerunner_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", "-shared", "-fPIC"]
+
+
+def sources():
+    d = os.path.join(PKG, "csrc")
+    return [os.path.join(d, f) for f in sorted(os.listdir(d))] + [os.path.join(PKG, "..", "include", "edgerunner_hip.h")]
+
+
+def up_to_date() -> bool:
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(s) <= t for s in sources())
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and up_to_date():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + ["-o", LIB, SRC]
+    if verbose:
+        print("[edgerunner_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=os.path.join(PKG, "csrc"))
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,1053 @@
+// C-ABI implementation (see include/edgerunner_hip.h): context, checkpoint loading,
+// KV cache, prefill, point encoder, device-side generation loop (hipGraph replay).
+// Single translation unit: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC.
+#include "../../include/edgerunner_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "er_common.h"
+#include "k_attn_decode.h"
+#include "k_gemm.h"
+#include "k_gemv.h"
+#include "k_head.h"
+#include "k_rowops.h"
+
+using namespace er;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ER_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define ERCHK(expr)                 \
+    do {                            \
+        int r_ = (expr);            \
+        if (r_ < 0) return r_;      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ context
+struct LayerW {
+    float *wqkv = nullptr, *bqkv = nullptr;   // fused [3*hidden][hidden] in q,k,v order
+    float *wo = nullptr, *bo = nullptr, *ln1w = nullptr, *ln1b = nullptr;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+};
+
+struct Buf {   // grow-only device scratch
+    float* p = nullptr;
+    size_t n = 0;
+};
+
+struct er_ctx {
+    er_config cfg{};
+    int device = 0;
+    int D = 0;               // head_dim
+    hipStream_t own_stream = nullptr;
+    // weights
+    std::vector<LayerW> layers;
+    float *embd = nullptr, *posemb = nullptr, *lm_head = nullptr, *embed_num_face = nullptr;
+    float *proj_w = nullptr, *proj_b = nullptr, *normc_w = nullptr, *normc_b = nullptr;
+    // point encoder
+    float *pe_query = nullptr, *pe_basis = nullptr, *pe_mlp_w = nullptr, *pe_mlp_b = nullptr, *pe_ln_w = nullptr,
+          *pe_ln_b = nullptr;
+    float *ca_ln1_w = nullptr, *ca_ln1_b = nullptr, *ca_ln2_w = nullptr, *ca_ln2_b = nullptr;
+    float *ca_q_w = nullptr, *ca_q_b = nullptr, *ca_k_w = nullptr, *ca_k_b = nullptr, *ca_v_w = nullptr, *ca_v_b = nullptr,
+          *ca_o_w = nullptr, *ca_o_b = nullptr;
+    float *ff0_w = nullptr, *ff0_b = nullptr, *ff2_w = nullptr, *ff2_b = nullptr, *lin_w = nullptr, *lin_b = nullptr;
+    int pe_kpad = 0;         // padded input width of point_embed.mlp (51 -> 64)
+    std::map<std::string, bool> need;   // required keys -> loaded?
+    std::vector<void*> owned;           // every hipMalloc'd weight block
+    // KV cache
+    int B = 0, Lcap = 0, S_splits = 0;
+    float *kc = nullptr, *vc = nullptr;       // [layers][B][H][Lcap][D]
+    long long kv_bstride = 0, kv_lstride = 0;
+    // decode workspace ([B][...])
+    float *ypre = nullptr, *hbuf = nullptr, *ypre1 = nullptr, *h1buf = nullptr, *qbuf = nullptr, *abuf = nullptr,
+          *fbuf = nullptr, *logits = nullptr, *part = nullptr;
+    int* state_block = nullptr;   // backing store of GenState
+    GenState st{};
+    DecodeParamsDev* d_params = nullptr;
+    int* d_ids_tmp = nullptr;
+    long long* d_out_ids = nullptr;   // [B][Lcap] generated ids (graph writes here; copied to the caller at the end)
+    int* h_pinned = nullptr;      // small pinned host buffer
+    int base_pos = 0;             // prefill length of the current generation
+    bool have_hidden = false;     // ypre holds a valid last-position state
+    // hipGraph of one step
+    hipGraphExec_t step_exec = nullptr;
+    bool use_graph = true;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_decode_ms = 0.f;
+    // scratch for prefill / encoder
+    Buf p_h, p_q, p_a, p_y, p_f, p_sc, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp;
+};
+
+static int ensure(Buf& b, size_t n) {
+    if (b.n >= n) return 0;
+    if (b.p) hipFree(b.p);
+    b.p = nullptr;
+    b.n = 0;
+    HIPCHK(hipMalloc(&b.p, n * sizeof(float)));
+    b.n = n;
+    return 0;
+}
+
+static hipStream_t pick(er_ctx* c, void* s) { return s ? (hipStream_t)s : c->own_stream; }
+
+extern "C" int er_abi_version(void) { return ER_ABI_VERSION; }
+extern "C" const char* er_last_error(void) { return g_err; }
+
+static const char* kKindNames[ER_NUM_KERNEL_KINDS] = {"qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv",
+                                                      "fc1_gemv", "fc2_gemv", "lm_head_gemv", "sample_head"};
+extern "C" const char* er_kernel_kind_name(int k) { return (k >= 0 && k < ER_NUM_KERNEL_KINDS) ? kKindNames[k] : "?"; }
+
+static void register_keys(er_ctx* c) {
+    auto& n = c->need;
+    const er_config& g = c->cfg;
+    auto lin = [&](const std::string& p, bool bias = true) {
+        n[p + ".weight"] = false;
+        if (bias) n[p + ".bias"] = false;
+    };
+    if (g.cond_mode == ER_COND_POINT) {
+        const std::string pe = "point_encoder";
+        n[pe + ".query_embed"] = false;
+        n[pe + ".point_embed.basis"] = false;
+        lin(pe + ".point_embed.mlp");
+        lin(pe + ".ln");
+        lin(pe + ".cross_att.ln1");
+        lin(pe + ".cross_att.ln2");
+        for (const char* p : {"q_proj", "k_proj", "v_proj", "out_proj"}) lin(pe + ".cross_att.att." + p);
+        lin(pe + ".cross_att.mlp.net.0");
+        lin(pe + ".cross_att.mlp.net.2");
+        lin(pe + ".linear");
+    }
+    if (g.cond_mode != ER_COND_NONE) {
+        lin("proj_cond");
+        lin("norm_cond");
+    }
+    if (g.num_face_buckets > 0) n["embed_num_face.weight"] = false;
+    n["mesh_decoder.model.embd.weight"] = false;
+    n["mesh_decoder.model.embed_positions.weight"] = false;
+    for (int i = 0; i < g.num_layers; ++i) {
+        const std::string L = "mesh_decoder.model.layers." + std::to_string(i);
+        for (const char* p : {"k_proj", "v_proj", "q_proj", "out_proj"}) lin(L + ".self_attn." + p);
+        lin(L + ".self_attn_layer_norm");
+        lin(L + ".fc1");
+        lin(L + ".fc2");
+        lin(L + ".final_layer_norm");
+    }
+    n["mesh_decoder.lm_head.weight"] = false;
+}
+
+static int dev_alloc(er_ctx* c, float** p, size_t n) {
+    HIPCHK(hipMalloc(p, n * sizeof(float)));
+    c->owned.push_back(*p);
+    return 0;
+}
+
+extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
+    if (!cfg || !out) return fail(ER_ERR_INVALID, "er_create: null argument");
+    if (cfg->hidden_dim != 1536 || cfg->intermediate_dim != 6144)
+        return fail(ER_ERR_UNSUPPORTED, "this build streams hidden_dim=1536 / intermediate_dim=6144 (ArAE, DiT presets); got %d/%d",
+                    cfg->hidden_dim, cfg->intermediate_dim);
+    if (cfg->num_heads <= 0 || cfg->hidden_dim % cfg->num_heads) return fail(ER_ERR_INVALID, "hidden_dim %% num_heads != 0");
+    const int D = cfg->hidden_dim / cfg->num_heads;
+    if (D != 96 && D != 64) return fail(ER_ERR_UNSUPPORTED, "head_dim %d not built (96, 64)", D);
+    if (cfg->weight_dtype != ER_F32 || cfg->kv_dtype != ER_F32)
+        return fail(ER_ERR_UNSUPPORTED, "only fp32 weights / fp32 KV (exact mode) are built in this round");
+    if (cfg->vocab_size > 1024) return fail(ER_ERR_UNSUPPORTED, "vocab_size > 1024");
+    if (cfg->cond_mode == ER_COND_POINT && (cfg->point_hidden_dim != 1024 || cfg->point_hidden_dim % cfg->point_num_heads))
+        return fail(ER_ERR_UNSUPPORTED, "point encoder width %d not built (1024)", cfg->point_hidden_dim);
+    HIPCHK(hipSetDevice(device));
+    er_ctx* c = new er_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    c->D = D;
+    c->layers.resize(cfg->num_layers);
+    const char* ng = getenv("ER_NO_GRAPH");
+    c->use_graph = !(ng && ng[0] == '1');
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipHostMalloc((void**)&c->h_pinned, 4096, hipHostMallocDefault));
+    register_keys(c);
+    *out = c;
+    return ER_OK;
+}
+
+static void free_kv(er_ctx* c) {
+    for (float* p : {c->kc, c->vc, c->ypre, c->hbuf, c->ypre1, c->h1buf, c->qbuf, c->abuf, c->fbuf, c->logits, c->part})
+        if (p) hipFree(p);
+    c->kc = c->vc = c->ypre = c->hbuf = c->ypre1 = c->h1buf = c->qbuf = c->abuf = c->fbuf = c->logits = c->part = nullptr;
+    if (c->state_block) hipFree(c->state_block);
+    if (c->d_params) hipFree(c->d_params);
+    if (c->d_ids_tmp) hipFree(c->d_ids_tmp);
+    if (c->d_out_ids) hipFree(c->d_out_ids);
+    c->d_out_ids = nullptr;
+    c->state_block = nullptr; c->d_params = nullptr; c->d_ids_tmp = nullptr;
+    if (c->step_exec) hipGraphExecDestroy(c->step_exec);
+    c->step_exec = nullptr;
+    c->B = 0; c->Lcap = 0;
+}
+
+extern "C" int er_destroy(er_ctx* c) {
+    if (!c) return ER_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    free_kv(c);
+    for (void* p : c->owned) hipFree(p);
+    for (Buf* b : {&c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
+                   &c->e_q, &c->e_sc, &c->e_att, &c->e_l, &c->e_ln, &c->e_u, &c->e_g, &c->e_lat, &c->e_tmp})
+        if (b->p) hipFree(b->p);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ weights
+static std::vector<float> to_f32_host(const void* data, int dtype, size_t n, int on_device, int* err) {
+    std::vector<float> out(n);
+    const size_t esz = (dtype == ER_F32) ? 4 : 2;
+    std::vector<unsigned char> raw;
+    const unsigned char* src = (const unsigned char*)data;
+    if (on_device) {
+        raw.resize(n * esz);
+        if (hipMemcpy(raw.data(), data, n * esz, hipMemcpyDeviceToHost) != hipSuccess) { *err = 1; return out; }
+        src = raw.data();
+    }
+    if (dtype == ER_F32) {
+        memcpy(out.data(), src, n * 4);
+    } else if (dtype == ER_BF16) {
+        const uint16_t* h = (const uint16_t*)src;
+        for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)h[i] << 16; memcpy(&out[i], &u, 4); }
+    } else {  // IEEE fp16
+        const uint16_t* h = (const uint16_t*)src;
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t s = (h[i] >> 15) & 1, e = (h[i] >> 10) & 31, m = h[i] & 1023;
+            uint32_t u;
+            if (e == 0) {
+                if (m == 0) u = s << 31;
+                else { int sh = 0; uint32_t mm = m; while (!(mm & 1024)) { mm <<= 1; ++sh; } u = (s << 31) | ((127 - 15 - sh + 1) << 23) | ((mm & 1023) << 13); }
+            } else if (e == 31) u = (s << 31) | 0x7f800000u | (m << 13);
+            else u = (s << 31) | ((e - 15 + 127) << 23) | (m << 13);
+            memcpy(&out[i], &u, 4);
+        }
+    }
+    return out;
+}
+
+static bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+extern "C" int er_load_tensor(er_ctx* c, const char* key_c, const void* data, int dtype, int ndim, const int64_t* shape,
+                              int on_device) {
+    if (!c || !key_c || !data || ndim < 1 || ndim > 4) return fail(ER_ERR_INVALID, "er_load_tensor: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    const std::string key(key_c);
+    auto it = c->need.find(key);
+    if (it == c->need.end()) return 1;   // strict=False: unknown keys are ignored
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    const er_config& g = c->cfg;
+    const int H = g.hidden_dim, I = g.intermediate_dim, PH = g.point_hidden_dim;
+    int err = 0;
+    std::vector<float> h = to_f32_host(data, dtype, n, on_device, &err);
+    if (err) return fail(ER_ERR_HIP, "er_load_tensor(%s): device read failed", key_c);
+
+    auto expect = [&](size_t want) -> int {
+        if (n != want) return fail(ER_ERR_INVALID, "er_load_tensor(%s): %zu elements, expected %zu", key_c, n, want);
+        return 0;
+    };
+    auto put = [&](float** dst, size_t want) -> int {   // plain copy into a fresh block
+        ERCHK(expect(want));
+        if (!*dst) ERCHK(dev_alloc(c, dst, want));
+        HIPCHK(hipMemcpy(*dst, h.data(), want * 4, hipMemcpyHostToDevice));
+        return 0;
+    };
+    auto put_at = [&](float** dst, size_t total, size_t off, size_t want) -> int {   // slice of a fused block
+        ERCHK(expect(want));
+        if (!*dst) { ERCHK(dev_alloc(c, dst, total)); HIPCHK(hipMemset(*dst, 0, total * 4)); }
+        HIPCHK(hipMemcpy(*dst + off, h.data(), want * 4, hipMemcpyHostToDevice));
+        return 0;
+    };
+
+    int rc = 0;
+    const std::string dec = "mesh_decoder.model.layers.";
+    if (key.rfind(dec, 0) == 0) {
+        const size_t dot = key.find('.', dec.size());
+        const int li = atoi(key.substr(dec.size(), dot - dec.size()).c_str());
+        if (li < 0 || li >= g.num_layers) return fail(ER_ERR_INVALID, "layer index out of range in %s", key_c);
+        LayerW& L = c->layers[li];
+        const std::string rest = key.substr(dot + 1);
+        const size_t HH = (size_t)H * H;
+        if (rest == "self_attn.q_proj.weight") rc = put_at(&L.wqkv, 3 * HH, 0, HH);
+        else if (rest == "self_attn.k_proj.weight") rc = put_at(&L.wqkv, 3 * HH, HH, HH);
+        else if (rest == "self_attn.v_proj.weight") rc = put_at(&L.wqkv, 3 * HH, 2 * HH, HH);
+        else if (rest == "self_attn.q_proj.bias") rc = put_at(&L.bqkv, 3 * H, 0, H);
+        else if (rest == "self_attn.k_proj.bias") rc = put_at(&L.bqkv, 3 * H, H, H);
+        else if (rest == "self_attn.v_proj.bias") rc = put_at(&L.bqkv, 3 * H, 2 * H, H);
+        else if (rest == "self_attn.out_proj.weight") rc = put(&L.wo, HH);
+        else if (rest == "self_attn.out_proj.bias") rc = put(&L.bo, H);
+        else if (rest == "self_attn_layer_norm.weight") rc = put(&L.ln1w, H);
+        else if (rest == "self_attn_layer_norm.bias") rc = put(&L.ln1b, H);
+        else if (rest == "fc1.weight") rc = put(&L.w1, (size_t)I * H);
+        else if (rest == "fc1.bias") rc = put(&L.b1, I);
+        else if (rest == "fc2.weight") rc = put(&L.w2, (size_t)H * I);
+        else if (rest == "fc2.bias") rc = put(&L.b2, H);
+        else if (rest == "final_layer_norm.weight") rc = put(&L.ln2w, H);
+        else if (rest == "final_layer_norm.bias") rc = put(&L.ln2b, H);
+        else return 1;
+    } else if (key == "mesh_decoder.model.embd.weight") rc = put(&c->embd, (size_t)g.vocab_size * H);
+    else if (key == "mesh_decoder.model.embed_positions.weight") rc = put(&c->posemb, (size_t)g.max_positions * H);
+    else if (key == "mesh_decoder.lm_head.weight") rc = put(&c->lm_head, (size_t)g.vocab_size * H);
+    else if (key == "embed_num_face.weight") rc = put(&c->embed_num_face, (size_t)g.num_face_buckets * H);
+    else if (key == "proj_cond.weight") rc = put(&c->proj_w, (size_t)H * g.point_latent_dim);
+    else if (key == "proj_cond.bias") rc = put(&c->proj_b, H);
+    else if (key == "norm_cond.weight") rc = put(&c->normc_w, H);
+    else if (key == "norm_cond.bias") rc = put(&c->normc_b, H);
+    else if (key == "point_encoder.query_embed") rc = put(&c->pe_query, (size_t)g.point_latent_size * PH);
+    else if (key == "point_encoder.point_embed.basis") rc = put(&c->pe_basis, (size_t)3 * g.point_freq_dim);
+    else if (key == "point_encoder.point_embed.mlp.weight") {
+        // [PH][2F+3] -> zero-padded [PH][kpad] so the GEMM K is a multiple of 16
+        const int kin = 2 * g.point_freq_dim + 3;
+        c->pe_kpad = (kin + 15) / 16 * 16;
+        ERCHK(expect((size_t)PH * kin));
+        std::vector<float> padded((size_t)PH * c->pe_kpad, 0.f);
+        for (int r = 0; r < PH; ++r) memcpy(&padded[(size_t)r * c->pe_kpad], &h[(size_t)r * kin], kin * 4);
+        if (!c->pe_mlp_w) ERCHK(dev_alloc(c, &c->pe_mlp_w, padded.size()));
+        HIPCHK(hipMemcpy(c->pe_mlp_w, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+    } else if (key == "point_encoder.point_embed.mlp.bias") rc = put(&c->pe_mlp_b, PH);
+    else if (key == "point_encoder.ln.weight") rc = put(&c->pe_ln_w, PH);
+    else if (key == "point_encoder.ln.bias") rc = put(&c->pe_ln_b, PH);
+    else if (key == "point_encoder.cross_att.ln1.weight") rc = put(&c->ca_ln1_w, PH);
+    else if (key == "point_encoder.cross_att.ln1.bias") rc = put(&c->ca_ln1_b, PH);
+    else if (key == "point_encoder.cross_att.ln2.weight") rc = put(&c->ca_ln2_w, PH);
+    else if (key == "point_encoder.cross_att.ln2.bias") rc = put(&c->ca_ln2_b, PH);
+    else if (key == "point_encoder.cross_att.att.q_proj.weight") rc = put(&c->ca_q_w, (size_t)PH * PH);
+    else if (key == "point_encoder.cross_att.att.q_proj.bias") rc = put(&c->ca_q_b, PH);
+    else if (key == "point_encoder.cross_att.att.k_proj.weight") rc = put(&c->ca_k_w, (size_t)PH * PH);
+    else if (key == "point_encoder.cross_att.att.k_proj.bias") rc = put(&c->ca_k_b, PH);
+    else if (key == "point_encoder.cross_att.att.v_proj.weight") rc = put(&c->ca_v_w, (size_t)PH * PH);
+    else if (key == "point_encoder.cross_att.att.v_proj.bias") rc = put(&c->ca_v_b, PH);
+    else if (key == "point_encoder.cross_att.att.out_proj.weight") rc = put(&c->ca_o_w, (size_t)PH * PH);
+    else if (key == "point_encoder.cross_att.att.out_proj.bias") rc = put(&c->ca_o_b, PH);
+    else if (key == "point_encoder.cross_att.mlp.net.0.weight") rc = put(&c->ff0_w, (size_t)8 * PH * PH);
+    else if (key == "point_encoder.cross_att.mlp.net.0.bias") rc = put(&c->ff0_b, (size_t)8 * PH);
+    else if (key == "point_encoder.cross_att.mlp.net.2.weight") rc = put(&c->ff2_w, (size_t)PH * 4 * PH);
+    else if (key == "point_encoder.cross_att.mlp.net.2.bias") rc = put(&c->ff2_b, PH);
+    else if (key == "point_encoder.linear.weight") rc = put(&c->lin_w, (size_t)g.point_latent_dim * PH);
+    else if (key == "point_encoder.linear.bias") rc = put(&c->lin_b, g.point_latent_dim);
+    else return 1;
+    if (rc < 0) return rc;
+    it->second = true;
+    (void)ends_with;
+    return ER_OK;
+}
+
+extern "C" int er_finalize_weights(er_ctx* c) {
+    if (!c) return fail(ER_ERR_INVALID, "null ctx");
+    for (auto& kv : c->need)
+        if (!kv.second) return fail(ER_ERR_MISSING, "tensor '%s' was never loaded", kv.first.c_str());
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ KV cache / workspace
+extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
+    if (!c || batch <= 0 || max_len <= 0) return fail(ER_ERR_INVALID, "er_kv_reserve: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    const er_config& g = c->cfg;
+    if (max_len > g.max_positions)
+        return fail(ER_ERR_CAPACITY, "max_len %d exceeds the position table (%d)", max_len, g.max_positions);
+    const int Lcap = (max_len + 31) / 32 * 32;
+    if (c->B == batch && c->Lcap == Lcap) return ER_OK;
+    HIPCHK(hipDeviceSynchronize());
+    free_kv(c);
+    const int H = g.num_heads, D = c->D, hid = g.hidden_dim;
+    c->kv_bstride = (long long)H * Lcap * D;
+    c->kv_lstride = c->kv_bstride * batch;
+    const size_t kv_elems = (size_t)c->kv_lstride * g.num_layers;
+    HIPCHK(hipMalloc(&c->kc, kv_elems * 4));
+    HIPCHK(hipMalloc(&c->vc, kv_elems * 4));
+    // split count of the decode attention: ~3 workgroups per CU at batch 1, fewer splits for large batches
+    int S = 48;
+    while (S > 4 && (long long)S * H * batch > 4096) S /= 2;
+    c->S_splits = S;
+    const size_t b = (size_t)batch;
+    HIPCHK(hipMalloc(&c->ypre, b * hid * 4));
+    HIPCHK(hipMalloc(&c->hbuf, b * hid * 4));
+    HIPCHK(hipMalloc(&c->ypre1, b * hid * 4));
+    HIPCHK(hipMalloc(&c->h1buf, b * hid * 4));
+    HIPCHK(hipMalloc(&c->qbuf, b * hid * 4));
+    HIPCHK(hipMalloc(&c->abuf, b * hid * 4));
+    HIPCHK(hipMalloc(&c->fbuf, b * g.intermediate_dim * 4));
+    HIPCHK(hipMalloc(&c->logits, b * g.vocab_size * 4));
+    HIPCHK(hipMalloc(&c->part, b * H * S * (D + 2) * 4));
+    HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
+    int* sb = c->state_block;
+    c->st.tok = sb; c->st.pos = sb + b; c->st.counter = sb + 2 * b; c->st.ngen = sb + 3 * b;
+    c->st.unfinished = sb + 4 * b; c->st.eos_step = sb + 5 * b; c->st.base_pos = sb + 6 * b; c->st.n_unfinished = sb + 7 * b;
+    HIPCHK(hipMalloc(&c->d_params, sizeof(DecodeParamsDev)));
+    HIPCHK(hipMalloc(&c->d_ids_tmp, b * sizeof(int)));
+    HIPCHK(hipMalloc(&c->d_out_ids, b * (size_t)Lcap * sizeof(long long)));
+    c->B = batch;
+    c->Lcap = Lcap;
+    c->have_hidden = false;
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ decode step
+struct StepPlan {   // which kinds to launch (profiling launches one kind at a time)
+    bool head = true, sample = true, layers = true;
+    int only_kind = -1;   // >= 0: launch just this kind
+    int only_layer = -1;
+};
+
+template <int KS, int RW, int PRO, int EPI>
+static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
+    // rows are processed in groups of 4/2/1 (K = 6144 keeps <= 2 rows of input in LDS)
+    const int maxnb = (KS == 1) ? 4 : 2;
+    int b = 0;
+    while (b < B) {
+        int nb = B - b;
+        nb = nb >= 4 ? 4 : (nb >= 2 ? 2 : 1);
+        if (nb > maxnb) nb = maxnb;
+        GemvArgs g = a;
+        if (g.xin) g.xin += (long long)b * K;
+        if (g.hout) g.hout += (long long)b * K;
+        if (g.tok) g.tok += b;
+        if (g.pos) g.pos += b;
+        if (g.out) g.out += (long long)b * a.N;
+        if (g.resid) g.resid += (long long)b * a.N;
+        if (g.q) g.q += (long long)b * a.hidden;
+        if (g.kcache) g.kcache += (long long)b * a.kv_bstride;
+        if (g.vcache) g.vcache += (long long)b * a.kv_bstride;
+        hipError_t e;
+        if (nb == 4) e = launch_gemv<6, KS, (KS == 1 ? 4 : 2), RW, PRO, EPI>(g, st);
+        else if (nb == 2) e = launch_gemv<6, KS, 2, RW, PRO, EPI>(g, st);
+        else e = launch_gemv<6, KS, 1, RW, PRO, EPI>(g, st);
+        if (e != hipSuccess) return e;
+        b += nb;
+    }
+    return hipSuccess;
+}
+
+static AttnDecArgs attn_args(er_ctx* c, int layer) {
+    AttnDecArgs a{};
+    a.q = c->qbuf;
+    a.kcache = c->kc + (long long)layer * c->kv_lstride;
+    a.vcache = c->vc + (long long)layer * c->kv_lstride;
+    a.pos = c->st.pos;
+    a.fixed_len = 0;
+    a.len_dev = nullptr;
+    a.part = c->part;
+    a.out = c->abuf;
+    a.H = c->cfg.num_heads;
+    a.l_cap = c->Lcap;
+    a.S = c->S_splits;
+    a.hidden = c->cfg.hidden_dim;
+    a.kv_bstride = c->kv_bstride;
+    a.sqrt_d = sqrtf((float)c->D);
+    return a;
+}
+
+static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int B, hipStream_t st) {
+    const int chunk_max = attn_chunk_max(a.l_cap, a.S);
+    const size_t lds = (size_t)(chunk_max + ER_NWAVES * D + 8) * sizeof(float);
+    if (D == 96) hipLaunchKernelGGL((attn_decode_f32_kernel<96>), dim3(a.S, a.H, B), dim3(ER_WG), lds, st, a, chunk_max);
+    else hipLaunchKernelGGL((attn_decode_f32_kernel<64>), dim3(a.S, a.H, B), dim3(ER_WG), lds, st, a, chunk_max);
+    return hipGetLastError();
+}
+static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int B, hipStream_t st) {
+    if (D == 96) hipLaunchKernelGGL((attn_combine_f32_kernel<96>), dim3(a.H, B), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((attn_combine_f32_kernel<64>), dim3(a.H, B), dim3(128), 0, st, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, long long* out_ids, int out_ld) {
+    const er_config& g = c->cfg;
+    const int H = g.hidden_dim, I = g.intermediate_dim, B = c->B;
+    const int nl = g.num_layers;
+    GemvArgs a{};
+    a.eps = g.ln_eps;
+    a.hidden = H; a.head_dim = c->D; a.l_cap = c->Lcap; a.kv_bstride = c->kv_bstride;
+    switch (kind) {
+        case 0: {   // qkv
+            const LayerW& L = c->layers[layer];
+            a.W = L.wqkv; a.bias = L.bqkv; a.N = 3 * H;
+            a.hout = c->hbuf; a.pos = c->st.pos;
+            a.q = c->qbuf;
+            a.kcache = c->kc + (long long)layer * c->kv_lstride;
+            a.vcache = c->vc + (long long)layer * c->kv_lstride;
+            if (layer == 0) {
+                a.embd = c->embd; a.posemb = c->posemb; a.tok = c->st.tok;
+                return gemv_groups<1, 2, PRO_EMBED, EPI_QKV>(a, B, H, st);
+            }
+            a.xin = c->ypre; a.ln_w = c->layers[layer - 1].ln2w; a.ln_b = c->layers[layer - 1].ln2b;
+            return gemv_groups<1, 2, PRO_LN, EPI_QKV>(a, B, H, st);
+        }
+        case 1: return launch_attn_partial(attn_args(c, layer), c->D, B, st);
+        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st);
+        case 3: {   // out_proj + bias + residual(h) -> ypre1
+            const LayerW& L = c->layers[layer];
+            a.W = L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
+            return gemv_groups<1, 1, PRO_NONE, EPI_RESID>(a, B, H, st);
+        }
+        case 4: {   // h1 = LN1(ypre1); f = relu(fc1 h1 + b)
+            const LayerW& L = c->layers[layer];
+            a.W = L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
+            a.hout = c->h1buf; a.out = c->fbuf;
+            return gemv_groups<1, 2, PRO_LN, EPI_RELU>(a, B, H, st);
+        }
+        case 5: {   // ypre = fc2 f + b + h1
+            const LayerW& L = c->layers[layer];
+            a.W = L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
+            return gemv_groups<4, 2, PRO_NONE, EPI_RESID>(a, B, I, st);
+        }
+        case 6: {   // logits = lm_head LN2_last(ypre)
+            a.W = c->lm_head; a.bias = nullptr; a.N = g.vocab_size; a.xin = c->ypre;
+            a.ln_w = c->layers[nl - 1].ln2w; a.ln_b = c->layers[nl - 1].ln2b; a.hout = nullptr; a.out = c->logits;
+            return gemv_groups<1, 1, PRO_LN, EPI_STORE>(a, B, H, st);
+        }
+        case 7:
+            hipLaunchKernelGGL(sample_head_kernel, dim3(B), dim3(ER_WG), sample_head_lds(g.vocab_size), st, c->logits,
+                               c->d_params, c->st, out_ids, out_ld);
+            return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t enqueue_layers(er_ctx* c, hipStream_t st) {
+    for (int l = 0; l < c->cfg.num_layers; ++l)
+        for (int k = 0; k <= 5; ++k) {
+            hipError_t e = launch_kind(c, k, l, st, nullptr, 0);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+static hipError_t enqueue_step(er_ctx* c, hipStream_t st, long long* out_ids, int out_ld) {
+    hipError_t e = launch_kind(c, 6, 0, st, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = launch_kind(c, 7, 0, st, out_ids, out_ld);
+    if (e != hipSuccess) return e;
+    return enqueue_layers(c, st);
+}
+
+// ------------------------------------------------------------------------------------ GEMM helpers (prefill / encoder)
+static hipError_t linear(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K,
+                         bool relu, const float* resid, int ldr, hipStream_t st) {
+    GemmArgs g = gemm_args_default();
+    g.A = A; g.B = W; g.C = C; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldr;
+    g.relu = relu ? 1 : 0;
+    return launch_gemm(g, 1, st);
+}
+
+#define HIPRET(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ER_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// softmax(Q K^T / sqrt(D)) V for one sample, all heads; scores live in `sc` ([H][N][ldS]).
+static int attention_full(const float* Q, int ldq, const float* Kp, int ldk, long long k_hstride, const float* Vp, int ldv,
+                          long long v_hstride, float* out, int ldo, float* sc, int H, int D, int N, int M, bool causal,
+                          hipStream_t st) {
+    const int ldS = (M + 15) / 16 * 16;
+    GemmArgs g = gemm_args_default();
+    g.A = Q; g.lda = ldq; g.sA2 = D;
+    g.B = Kp; g.ldb = ldk; g.sB2 = k_hstride;
+    g.C = sc; g.ldc = ldS; g.sC2 = (long long)N * ldS;
+    g.Z2 = H; g.M = N; g.N = M; g.K = D; g.div = sqrtf((float)D);
+    g.causal = causal ? 1 : 0; g.causal_off = M - N;
+    HIPRET(launch_gemm(g, H, st));
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(N, H), dim3(ER_WG), 0, st, sc, N, M, (long long)ldS, ldS,
+                       (long long)N * ldS, causal ? 1 : 0, M - N);
+    HIPRET(hipGetLastError());
+    GemmArgs p = gemm_args_default();
+    p.A = sc; p.lda = ldS; p.sA2 = (long long)N * ldS;
+    p.B = Vp; p.ldb = ldv; p.sB2 = v_hstride; p.b_is_kn = 1; p.kb_valid = M;
+    p.C = out; p.ldc = ldo; p.sC2 = D;
+    p.Z2 = H; p.M = N; p.N = D; p.K = ldS;
+    p.causal = causal ? 1 : 0; p.causal_off = M - N;
+    HIPRET(launch_gemm(p, H, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ encode_cond
+extern "C" int er_encode_cond(er_ctx* c, const float* conds, int B, int n_points, const int32_t* face_bucket,
+                              float* cond_out, void* stream) {
+    if (!c || !cond_out || B <= 0) return fail(ER_ERR_INVALID, "er_encode_cond: bad argument");
+    ERCHK(er_finalize_weights(c));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick(c, stream);
+    const er_config& g = c->cfg;
+    const int H = g.hidden_dim, C = g.num_cond_tokens, PH = g.point_hidden_dim, Lq = g.point_latent_size, LD = g.point_latent_dim;
+    const int n_lat = (g.cond_mode == ER_COND_NONE) ? 0 : Lq;
+    const int n_face = g.num_face_buckets > 0 ? 1 : 0;
+    if (n_lat + n_face != C) return fail(ER_ERR_INVALID, "num_cond_tokens %d != latent tokens %d + face token %d", C, n_lat, n_face);
+    if (g.cond_mode != ER_COND_NONE && !conds) return fail(ER_ERR_INVALID, "er_encode_cond: conds is null");
+    if (LD % 16) return fail(ER_ERR_UNSUPPORTED, "point_latent_dim must be a multiple of 16");
+
+    for (int b = 0; b < B; ++b) {
+        const float* lat = nullptr;   // [Lq][LD]
+        if (g.cond_mode == ER_COND_POINT) {
+            const int N = n_points;
+            if (N <= 0) return fail(ER_ERR_INVALID, "n_points must be > 0");
+            const int PHh = g.point_num_heads, PD = PH / PHh;
+            const int ldS = (N + 15) / 16 * 16;
+            ERCHK(ensure(c->e_a0, (size_t)N * c->pe_kpad));
+            ERCHK(ensure(c->e_x, (size_t)N * PH));
+            ERCHK(ensure(c->e_k, (size_t)N * PH));
+            ERCHK(ensure(c->e_v, (size_t)N * PH));
+            ERCHK(ensure(c->e_qln, (size_t)Lq * PH));
+            ERCHK(ensure(c->e_q, (size_t)Lq * PH));
+            ERCHK(ensure(c->e_sc, (size_t)PHh * Lq * ldS));
+            ERCHK(ensure(c->e_att, (size_t)Lq * PH));
+            ERCHK(ensure(c->e_l, (size_t)Lq * PH));
+            ERCHK(ensure(c->e_ln, (size_t)Lq * PH));
+            ERCHK(ensure(c->e_u, (size_t)Lq * 8 * PH));
+            ERCHK(ensure(c->e_g, (size_t)Lq * 4 * PH));
+            ERCHK(ensure(c->e_lat, (size_t)Lq * LD));
+            const float* pts = conds + (size_t)b * N * 3;
+            // x = ln(point_embed(pts))                                          point.py:194
+            hipLaunchKernelGGL(point_embed_kernel, dim3(ew_grid((long long)N * c->pe_kpad)), dim3(ER_WG), 0, st, pts,
+                               c->pe_basis, c->e_a0.p, (long long)N, g.point_freq_dim, c->pe_kpad);
+            HIPRET(hipGetLastError());
+            HIPRET(linear(c->e_a0.p, c->pe_kpad, c->pe_mlp_w, c->pe_mlp_b, c->e_x.p, PH, N, PH, c->pe_kpad, false, nullptr, 0, st));
+            HIPRET(launch_layernorm(c->e_x.p, c->pe_ln_w, c->pe_ln_b, c->e_x.p, N, PH, PH, PH, g.ln_eps, st));
+            // cross attention: l = q + out_proj(attn(q_proj(ln1(q)), k_proj(x), v_proj(x)))   point.py:123-124
+            HIPRET(launch_layernorm(c->pe_query, c->ca_ln1_w, c->ca_ln1_b, c->e_qln.p, Lq, PH, PH, PH, g.ln_eps, st));
+            HIPRET(linear(c->e_qln.p, PH, c->ca_q_w, c->ca_q_b, c->e_q.p, PH, Lq, PH, PH, false, nullptr, 0, st));
+            HIPRET(linear(c->e_x.p, PH, c->ca_k_w, c->ca_k_b, c->e_k.p, PH, N, PH, PH, false, nullptr, 0, st));
+            HIPRET(linear(c->e_x.p, PH, c->ca_v_w, c->ca_v_b, c->e_v.p, PH, N, PH, PH, false, nullptr, 0, st));
+            ERCHK(attention_full(c->e_q.p, PH, c->e_k.p, PH, PD, c->e_v.p, PH, PD, c->e_att.p, PH, c->e_sc.p, PHh, PD, Lq, N,
+                                 false, st));
+            HIPRET(linear(c->e_att.p, PH, c->ca_o_w, c->ca_o_b, c->e_l.p, PH, Lq, PH, PH, false, c->pe_query, PH, st));
+            // l = l + net2(GEGLU(net0(ln2(l))))                                   point.py:125, 68-84
+            HIPRET(launch_layernorm(c->e_l.p, c->ca_ln2_w, c->ca_ln2_b, c->e_ln.p, Lq, PH, PH, PH, g.ln_eps, st));
+            HIPRET(linear(c->e_ln.p, PH, c->ff0_w, c->ff0_b, c->e_u.p, 8 * PH, Lq, 8 * PH, PH, false, nullptr, 0, st));
+            hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)Lq * 4 * PH)), dim3(ER_WG), 0, st, c->e_u.p, c->e_g.p,
+                               (long long)Lq, 4 * PH);
+            HIPRET(hipGetLastError());
+            HIPRET(linear(c->e_g.p, 4 * PH, c->ff2_w, c->ff2_b, c->e_l.p, PH, Lq, PH, 4 * PH, false, c->e_l.p, PH, st));
+            // latent mean = linear(l)                                              point.py:201
+            HIPRET(linear(c->e_l.p, PH, c->lin_w, c->lin_b, c->e_lat.p, LD, Lq, LD, PH, false, nullptr, 0, st));
+            lat = c->e_lat.p;
+        } else if (g.cond_mode == ER_COND_POINT_LATENT) {
+            lat = conds + (size_t)b * Lq * LD;
+        }
+        float* out_b = cond_out + (size_t)b * C * H;
+        if (lat) {   // norm_cond(proj_cond(latent))                               core/models.py:124 / 128-129
+            ERCHK(ensure(c->e_tmp, (size_t)Lq * H));
+            HIPRET(linear(lat, LD, c->proj_w, c->proj_b, c->e_tmp.p, H, Lq, H, LD, false, nullptr, 0, st));
+            HIPRET(launch_layernorm(c->e_tmp.p, c->normc_w, c->normc_b, out_b, Lq, H, H, H, g.ln_eps, st));
+        }
+        if (n_face) {   // embed_num_face(quantize_num_faces(n))                     core/models.py:135-139
+            const int bucket = face_bucket ? face_bucket[b] : 0;
+            if (bucket < 0 || bucket >= g.num_face_buckets) return fail(ER_ERR_INVALID, "face bucket %d out of range", bucket);
+            HIPCHK(hipMemcpyAsync(out_b + (size_t)n_lat * H, c->embed_num_face + (size_t)bucket * H, (size_t)H * 4,
+                                  hipMemcpyDeviceToDevice, st));
+        }
+    }
+    return ER_OK;
+}
+
+extern "C" int er_embed_tokens(er_ctx* c, const int32_t* ids, int B, int R, float* out, void* stream) {
+    if (!c || !ids || !out || B <= 0 || R <= 0) return fail(ER_ERR_INVALID, "er_embed_tokens: bad argument");
+    ERCHK(er_finalize_weights(c));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick(c, stream);
+    const int H = c->cfg.hidden_dim;
+    for (int i = 0; i < B * R; ++i) {
+        if (ids[i] < 0 || ids[i] >= c->cfg.vocab_size) return fail(ER_ERR_INVALID, "token id %d out of range", ids[i]);
+        HIPCHK(hipMemcpyAsync(out + (size_t)i * H, c->embd + (size_t)ids[i] * H, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ prefill
+extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* stream) {
+    if (!c || !embeds || B <= 0 || S <= 0) return fail(ER_ERR_INVALID, "er_prefill: bad argument");
+    ERCHK(er_finalize_weights(c));
+    if (c->B != B) return fail(ER_ERR_INVALID, "er_prefill: batch %d but KV cache reserved for %d (call er_kv_reserve)", B, c->B);
+    if (S >= c->Lcap) return fail(ER_ERR_CAPACITY, "prefix length %d does not fit the reserved KV cache (%d)", S, c->Lcap);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick(c, stream);
+    const er_config& g = c->cfg;
+    const int H = g.hidden_dim, I = g.intermediate_dim, NH = g.num_heads, D = c->D;
+    const int M = B * S;
+    const int ldS = (S + 15) / 16 * 16;
+    ERCHK(ensure(c->p_h, (size_t)M * H));
+    ERCHK(ensure(c->p_q, (size_t)M * H));
+    ERCHK(ensure(c->p_a, (size_t)M * H));
+    ERCHK(ensure(c->p_y, (size_t)M * H));
+    ERCHK(ensure(c->p_f, (size_t)M * I));
+    ERCHK(ensure(c->p_sc, (size_t)NH * S * ldS));
+    float *h = c->p_h.p, *q = c->p_q.p, *a = c->p_a.p, *y = c->p_y.p, *f = c->p_f.p;
+
+    // hidden = inputs_embeds + pos_embeds(0..S)                       modeling_opt.py:355-357
+    hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid((long long)M * H / 4)), dim3(ER_WG), 0, st, embeds, c->posemb, h, B, S, H, 0);
+    HIPRET(hipGetLastError());
+    for (int l = 0; l < g.num_layers; ++l) {
+        const LayerW& L = c->layers[l];
+        float* kc = c->kc + (long long)l * c->kv_lstride;
+        float* vc = c->vc + (long long)l * c->kv_lstride;
+        // q,k,v projections; k,v go straight into the cache layout      modeling_opt.py:185-196
+        GemmArgs qa = gemm_args_default();
+        qa.A = h; qa.lda = H; qa.B = L.wqkv; qa.ldb = H; qa.bias = L.bqkv; qa.C = q; qa.ldc = H;
+        qa.M = M; qa.N = 3 * H; qa.K = H; qa.epi = GEPI_QKV;
+        qa.q = q; qa.kcache = kc; qa.vcache = vc; qa.S = S; qa.hidden = H; qa.head_dim = D; qa.l_cap = c->Lcap;
+        qa.kv_bstride = c->kv_bstride;
+        HIPRET(launch_gemm(qa, 1, st));
+        for (int b = 0; b < B; ++b)   // causal attention over the prefix     modeling_opt.py:229
+            ERCHK(attention_full(q + (size_t)b * S * H, H, kc + b * c->kv_bstride, D, (long long)c->Lcap * D,
+                                 vc + b * c->kv_bstride, D, (long long)c->Lcap * D, a + (size_t)b * S * H, H, c->p_sc.p, NH, D, S,
+                                 S, true, st));
+        // y = h + out_proj(a); h1 = LN1(y)                               modeling_opt.py:232, 272-274
+        HIPRET(linear(a, H, L.wo, L.bo, y, H, M, H, H, false, h, H, st));
+        HIPRET(launch_layernorm(y, L.ln1w, L.ln1b, h, M, H, H, H, g.ln_eps, st));
+        // y = h1 + fc2(relu(fc1(h1))); h = LN2(y)                        modeling_opt.py:281-288
+        HIPRET(linear(h, H, L.w1, L.b1, f, I, M, I, H, true, nullptr, 0, st));
+        HIPRET(linear(f, I, L.w2, L.b2, y, H, M, H, I, false, h, H, st));
+        if (l + 1 < g.num_layers) HIPRET(launch_layernorm(y, L.ln2w, L.ln2b, h, M, H, H, H, g.ln_eps, st));
+    }
+    // keep the last position's pre-LN2 state: the decode head applies LN2 + lm_head to it
+    for (int b = 0; b < B; ++b)
+        HIPCHK(hipMemcpyAsync(c->ypre + (size_t)b * H, y + ((size_t)b * S + S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(init_state_kernel, dim3((B + 63) / 64), dim3(64), 0, st, c->st, B, S);
+    HIPRET(hipGetLastError());
+    c->base_pos = S;
+    c->have_hidden = true;
+    return ER_OK;
+}
+
+extern "C" int er_logits(er_ctx* c, float* out, void* stream) {
+    if (!c || !out) return fail(ER_ERR_INVALID, "er_logits: bad argument");
+    if (!c->have_hidden) return fail(ER_ERR_INVALID, "er_logits: no forward pass has run (call er_prefill)");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick(c, stream);
+    HIPRET(launch_kind(c, 6, 0, st, nullptr, 0));
+    HIPCHK(hipMemcpyAsync(out, c->logits, (size_t)c->B * c->cfg.vocab_size * 4, hipMemcpyDeviceToDevice, st));
+    return ER_OK;
+}
+
+static int check_room(er_ctx* c, int extra) {
+    // generated token t is fed at position base_pos + t
+    HIPCHK(hipMemcpy(c->h_pinned, c->st.ngen, sizeof(int), hipMemcpyDeviceToHost));
+    const int used = c->base_pos + c->h_pinned[0];
+    if (used + extra > c->Lcap) return fail(ER_ERR_CAPACITY, "KV cache full: %d + %d > %d", used, extra, c->Lcap);
+    if (used + extra > c->cfg.max_positions) return fail(ER_ERR_CAPACITY, "position table exhausted (%d)", c->cfg.max_positions);
+    return 0;
+}
+
+extern "C" int er_feed(er_ctx* c, const int32_t* ids, void* stream) {
+    if (!c || !ids) return fail(ER_ERR_INVALID, "er_feed: bad argument");
+    if (!c->have_hidden) return fail(ER_ERR_INVALID, "er_feed: call er_prefill first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick(c, stream);
+    HIPCHK(hipStreamSynchronize(st));
+    ERCHK(check_room(c, 1));
+    if (c->B > 1024) return fail(ER_ERR_UNSUPPORTED, "batch > 1024");
+    for (int b = 0; b < c->B; ++b) {
+        if (ids[b] < 0 || ids[b] >= c->cfg.vocab_size) return fail(ER_ERR_INVALID, "token id %d out of range", ids[b]);
+        c->h_pinned[b] = ids[b];
+    }
+    HIPCHK(hipMemcpyAsync(c->d_ids_tmp, c->h_pinned, c->B * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(force_token_kernel, dim3((c->B + 63) / 64), dim3(64), 0, st, c->d_ids_tmp, c->st, c->B);
+    HIPRET(hipGetLastError());
+    HIPRET(enqueue_layers(c, st));
+    HIPCHK(hipStreamSynchronize(st));   // h_pinned may be reused by the next call
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ generation loop
+__global__ void fill_i64_kernel(long long* p, long long n, long long v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void reset_gen_kernel(GenState st, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *st.n_unfinished = B;
+    if (b >= B) return;
+    st.counter[b] = 0; st.unfinished[b] = 1; st.eos_step[b] = -1;
+}
+
+extern "C" int er_decode(er_ctx* c, const er_decode_params* p, int64_t* out_ids, int32_t* n_steps, void* stream) {
+    if (!c || !p || !out_ids || !n_steps) return fail(ER_ERR_INVALID, "er_decode: bad argument");
+    if (!c->have_hidden) return fail(ER_ERR_INVALID, "er_decode: call er_prefill first");
+    if (p->max_new_tokens <= 0) return fail(ER_ERR_INVALID, "max_new_tokens must be > 0");
+    if (p->mode != ER_GREEDY && p->mode != ER_SAMPLE) return fail(ER_ERR_INVALID, "bad mode");
+    if (p->grammar < 0 || p->grammar > 2) return fail(ER_ERR_INVALID, "bad grammar");
+    if (p->mode == ER_SAMPLE && p->top_k <= 0) return fail(ER_ERR_INVALID, "top_k must be > 0 in sample mode");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick(c, stream);
+    const int B = c->B, T = p->max_new_tokens;
+    HIPCHK(hipStreamSynchronize(st));
+    ERCHK(check_room(c, T));
+    if (c->h_pinned[0] != 0) return fail(ER_ERR_INVALID, "er_decode must directly follow er_prefill (%d tokens already fed)", c->h_pinned[0]);
+
+    DecodeParamsDev dp{};
+    dp.mode = p->mode; dp.top_k = p->top_k; dp.grammar = p->grammar; dp.max_new = T; dp.min_new = p->min_new_tokens;
+    dp.eos = c->cfg.eos_token_id; dp.pad = c->cfg.pad_token_id; dp.vocab = c->cfg.vocab_size;
+    dp.seed_lo = (unsigned int)(p->seed & 0xffffffffu); dp.seed_hi = (unsigned int)(p->seed >> 32);
+    HIPCHK(hipMemcpy(c->d_params, &dp, sizeof(dp), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(reset_gen_kernel, dim3((B + 63) / 64), dim3(64), 0, st, c->st, B);
+    HIPRET(hipGetLastError());
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(ew_grid((long long)B * c->Lcap)), dim3(ER_WG), 0, st, c->d_out_ids,
+                       (long long)B * c->Lcap, (long long)dp.pad);
+    HIPRET(hipGetLastError());
+
+    // one step = lm_head -> sampling head -> 24 layers on the chosen token; captured once, replayed T times
+    if (c->use_graph && !c->step_exec) {
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeRelaxed));
+        hipError_t e = enqueue_step(c, c->own_stream, c->d_out_ids, c->Lcap);
+        hipError_t e2 = hipStreamEndCapture(c->own_stream, &graph);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            if (graph) hipGraphDestroy(graph);
+            return fail(ER_ERR_HIP, "graph capture failed: %s / %s", hipGetErrorString(e), hipGetErrorString(e2));
+        }
+        HIPCHK(hipGraphInstantiate(&c->step_exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+    }
+
+    const int check_every = 32;
+    int steps_run = 0;
+    bool all_done = false;
+    HIPCHK(hipEventRecord(c->ev0, st));
+    for (int t = 0; t < T; ++t) {
+        if (c->use_graph) HIPCHK(hipGraphLaunch(c->step_exec, st));
+        else HIPRET(enqueue_step(c, st, c->d_out_ids, c->Lcap));
+        steps_run = t + 1;
+        if (steps_run >= p->min_new_tokens && steps_run < T && (steps_run % check_every) == 0) {
+            HIPCHK(hipMemcpyAsync(c->h_pinned, c->st.n_unfinished, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (c->h_pinned[0] <= 0) { all_done = true; break; }
+        }
+    }
+    HIPCHK(hipEventRecord(c->ev1, st));
+    HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)T * sizeof(long long), c->d_out_ids, (size_t)c->Lcap * sizeof(long long),
+                            (size_t)T * sizeof(long long), B, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->h_pinned, c->st.eos_step, B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&c->last_decode_ms, c->ev0, c->ev1));
+    (void)all_done;
+    // HF returns as many columns as steps it ran: it stops right after the step in which the last row emits EOS
+    int last = -1;
+    bool finished = true;
+    for (int b = 0; b < B; ++b) {
+        if (c->h_pinned[b] < 0) finished = false;
+        else if (c->h_pinned[b] > last) last = c->h_pinned[b];
+    }
+    *n_steps = finished ? last + 1 : T;
+    if (!finished && steps_run < T) return fail(ER_ERR_INVALID, "internal: stopped early with unfinished rows");
+    return ER_OK;
+}
+
+extern "C" int er_last_decode_ms(er_ctx* c, float* ms) {
+    if (!c || !ms) return fail(ER_ERR_INVALID, "null");
+    *ms = c->last_decode_ms;
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ per-kernel timing
+extern "C" int er_profile_decode_kernels(er_ctx* c, int repeats, float* avg_us, double* bytes, void* stream) {
+    if (!c || !avg_us || !bytes || repeats <= 0) return fail(ER_ERR_INVALID, "er_profile_decode_kernels: bad argument");
+    if (!c->have_hidden) return fail(ER_ERR_INVALID, "profile: call er_prefill first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = pick(c, stream);
+    const er_config& g = c->cfg;
+    const int B = c->B, H = g.hidden_dim, I = g.intermediate_dim, nl = g.num_layers, V = g.vocab_size;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(c->h_pinned, c->st.pos, sizeof(int), hipMemcpyDeviceToHost));
+    const double len = (double)c->h_pinned[0] + 1.0;
+    // save the state the sweep scribbles on
+    std::vector<float> save_y((size_t)B * H);
+    HIPCHK(hipMemcpy(save_y.data(), c->ypre, save_y.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int> save_state(7 * (size_t)B + 8);
+    HIPCHK(hipMemcpy(save_state.data(), c->state_block, save_state.size() * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> head_state = save_state;          // the head sweep runs at step 0 so it writes dummy_ids[b][0]
+    for (int b = 0; b < B; ++b) head_state[3 * (size_t)B + b] = 0;
+    DecodeParamsDev dp{};
+    dp.mode = 0; dp.top_k = 10; dp.grammar = 2; dp.max_new = 1 << 30; dp.min_new = 0;
+    dp.eos = g.eos_token_id; dp.pad = g.pad_token_id; dp.vocab = V;
+    HIPCHK(hipMemcpy(c->d_params, &dp, sizeof(dp), hipMemcpyHostToDevice));
+    long long* dummy_ids = nullptr;
+    HIPCHK(hipMalloc(&dummy_ids, (size_t)B * 8 * sizeof(long long)));
+
+    const double w = 4.0;
+    bytes[0] = ((double)3 * H * H + 3 * H) * w + (double)B * (H + 3 * H) * w;
+    bytes[1] = (double)B * 2.0 * len * H * w;
+    bytes[2] = (double)B * g.num_heads * c->S_splits * (c->D + 2) * w + (double)B * H * w;
+    bytes[3] = ((double)H * H + H) * w + (double)B * 3 * H * w;
+    bytes[4] = ((double)I * H + I) * w + (double)B * (H + I) * w;
+    bytes[5] = ((double)I * H + H) * w + (double)B * (I + 2 * H) * w;
+    bytes[6] = ((double)V * H) * w + (double)B * (H + V) * w;
+    bytes[7] = (double)B * V * w;
+
+    for (int kind = 0; kind < ER_NUM_KERNEL_KINDS; ++kind) {
+        const bool per_layer = kind <= 5;
+        // warm-up + timed sweeps
+        for (int pass = 0; pass < 2; ++pass) {
+            const int reps = pass == 0 ? 1 : repeats;
+            if (pass == 1) HIPCHK(hipEventRecord(c->ev0, st));
+            int launches = 0;
+            for (int r = 0; r < reps; ++r) {
+                if (per_layer) {
+                    for (int l = 0; l < nl; ++l) { HIPRET(launch_kind(c, kind, l, st, dummy_ids, 8)); ++launches; }
+                } else {
+                    for (int l = 0; l < nl; ++l) {   // same number of back-to-back launches
+                        if (kind == 7) {   // keep the head's step counter in range
+                            HIPCHK(hipMemcpyAsync(c->state_block, head_state.data(), head_state.size() * sizeof(int), hipMemcpyHostToDevice, st));
+                        }
+                        HIPRET(launch_kind(c, kind, 0, st, dummy_ids, 8));
+                        ++launches;
+                    }
+                }
+            }
+            if (pass == 1) {
+                HIPCHK(hipEventRecord(c->ev1, st));
+                HIPCHK(hipStreamSynchronize(st));
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+                avg_us[kind] = ms * 1000.0f / (float)launches;
+            }
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(c->ypre, save_y.data(), save_y.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->state_block, save_state.data(), save_state.size() * sizeof(int), hipMemcpyHostToDevice));
+    hipFree(dummy_ids);
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ single-kernel entry points
+extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, const float* ln_w, const float* ln_b,
+                         const float* resid, float* y, float* xnorm_out, int B, int n, int k, int relu, float eps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GemvArgs a{};
+    a.W = w; a.bias = bias; a.N = n; a.xin = x; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.hout = xnorm_out;
+    a.out = y; a.resid = resid;
+    hipError_t e;
+    if (k == 1536) {
+        if (ln_w && relu && !resid) e = gemv_groups<1, 2, PRO_LN, EPI_RELU>(a, B, k, st);
+        else if (ln_w && !relu && !resid) e = gemv_groups<1, 1, PRO_LN, EPI_STORE>(a, B, k, st);
+        else if (!ln_w && !relu && resid) e = gemv_groups<1, 1, PRO_NONE, EPI_RESID>(a, B, k, st);
+        else return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: combination not instantiated for k=1536");
+    } else if (k == 6144) {
+        if (!ln_w && !relu && resid) e = gemv_groups<4, 2, PRO_NONE, EPI_RESID>(a, B, k, st);
+        else return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: combination not instantiated for k=6144");
+    } else {
+        return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: k must be 1536 or 6144");
+    }
+    HIPRET(e);
+    return ER_OK;
+}
+
+extern "C" int er_k_attn_decode(const float* q, const float* k, const float* v, const int32_t* len_host, float* out, int B,
+                                int heads, int head_dim, int l_cap, int splits, void* stream) {
+    if (head_dim != 96 && head_dim != 64) return fail(ER_ERR_UNSUPPORTED, "head_dim %d", head_dim);
+    hipStream_t st = (hipStream_t)stream;
+    int* len_dev = nullptr;
+    float* part = nullptr;
+    HIPCHK(hipMalloc(&len_dev, B * sizeof(int)));
+    HIPCHK(hipMalloc(&part, (size_t)B * heads * splits * (head_dim + 2) * 4));
+    HIPCHK(hipMemcpy(len_dev, len_host, B * sizeof(int), hipMemcpyHostToDevice));
+    AttnDecArgs a{};
+    a.q = q; a.kcache = k; a.vcache = v; a.len_dev = len_dev; a.part = part; a.out = out;
+    a.H = heads; a.l_cap = l_cap; a.S = splits; a.hidden = heads * head_dim;
+    a.kv_bstride = (long long)heads * l_cap * head_dim; a.sqrt_d = sqrtf((float)head_dim);
+    hipError_t e = launch_attn_partial(a, head_dim, B, st);
+    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(len_dev);
+    hipFree(part);
+    HIPRET(e);
+    HIPRET(e2);
+    return ER_OK;
+}
+
+extern "C" int er_k_gemm(const float* a, const float* b, const float* bias, const float* resid, float* cc, int m, int n, int k,
+                         int lda, int ldb, int ldc, int b_is_kn, int relu, float div, void* stream) {
+    if (k % 16) return fail(ER_ERR_INVALID, "er_k_gemm: k must be a multiple of 16");
+    GemmArgs g = gemm_args_default();
+    g.A = a; g.B = b; g.C = cc; g.bias = bias; g.resid = resid; g.M = m; g.N = n; g.K = k;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.b_is_kn = b_is_kn; g.kb_valid = k; g.relu = relu; g.div = div;
+    HIPRET(launch_gemm(g, 1, (hipStream_t)stream));
+    return ER_OK;
+}
+
+extern "C" int er_k_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int cols, float eps, void* stream) {
+    HIPRET(launch_layernorm(x, w, b, y, rows, cols, cols, cols, eps, (hipStream_t)stream));
+    return ER_OK;
+}
+
+extern "C" int er_k_softmax(float* s, int rows, int cols, int ld, int causal, void* stream) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows, 1), dim3(ER_WG), 0, (hipStream_t)stream, s, rows, cols, (long long)ld, ld,
+                       0LL, causal, 0);
+    HIPRET(hipGetLastError());
+    return ER_OK;
+}
+
+extern "C" int er_k_sample_head(const float* logits, const er_decode_params* p, int vocab, int eos, int pad, int B, int step,
+                                const int32_t* last_tok, const int32_t* counter, const int32_t* unfinished, int32_t* next_tok,
+                                int32_t* counter_out, int32_t* unfinished_out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const size_t b = (size_t)B;
+    int* sb = nullptr;
+    DecodeParamsDev* dpd = nullptr;
+    long long* ids = nullptr;
+    HIPCHK(hipMalloc(&sb, (7 * b + 8) * sizeof(int)));
+    HIPCHK(hipMalloc(&dpd, sizeof(DecodeParamsDev)));
+    HIPCHK(hipMalloc(&ids, b * (size_t)(step + 1) * sizeof(long long)));
+    std::vector<int> h(7 * b + 8, 0);
+    for (size_t i = 0; i < b; ++i) {
+        h[i] = last_tok[i]; h[b + i] = 0; h[2 * b + i] = counter[i]; h[3 * b + i] = step;
+        h[4 * b + i] = unfinished[i]; h[5 * b + i] = -1; h[6 * b + i] = 0;
+    }
+    h[7 * b] = B;
+    HIPCHK(hipMemcpy(sb, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+    GenState s{};
+    s.tok = sb; s.pos = sb + b; s.counter = sb + 2 * b; s.ngen = sb + 3 * b; s.unfinished = sb + 4 * b;
+    s.eos_step = sb + 5 * b; s.base_pos = sb + 6 * b; s.n_unfinished = sb + 7 * b;
+    DecodeParamsDev dp{};
+    dp.mode = p->mode; dp.top_k = p->top_k; dp.grammar = p->grammar; dp.max_new = step + 1; dp.min_new = p->min_new_tokens;
+    dp.eos = eos; dp.pad = pad; dp.vocab = vocab;
+    dp.seed_lo = (unsigned int)(p->seed & 0xffffffffu); dp.seed_hi = (unsigned int)(p->seed >> 32);
+    HIPCHK(hipMemcpy(dpd, &dp, sizeof(dp), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sample_head_kernel, dim3(B), dim3(ER_WG), sample_head_lds(vocab), st, logits, dpd, s, ids, step + 1);
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(st);
+    if (e == hipSuccess && e2 == hipSuccess) {
+        hipMemcpy(h.data(), sb, h.size() * sizeof(int), hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < b; ++i) { next_tok[i] = h[i]; counter_out[i] = h[2 * b + i]; unfinished_out[i] = h[4 * b + i]; }
+    }
+    hipFree(sb); hipFree(dpd); hipFree(ids);
+    HIPRET(e);
+    HIPRET(e2);
+    return ER_OK;
+}

@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, 256-thread workgroups).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define ER_WAVE 64
+#define ER_WG 256          // threads per workgroup used by every kernel here
+#define ER_NWAVES 4        // ER_WG / ER_WAVE
+
+namespace er {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: usable with nontemporal builtins / MFMA
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide (4 waves) reductions through a 4-float LDS scratch.  Every thread
+// returns the same value (partials are combined in a fixed order).
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b, float acc) {
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+}  // namespace er

@@ -1,0 +1,194 @@
+// fp32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: an exact,
+// k-ordered fmaf chain at the fp32 vector rate) for the once-per-sample work:
+// the 2050-token prefill (core/transformer/modeling_opt.py:321-426 with
+// inputs_embeds) and the point-cloud encoder (core/transformer/point.py:186-206).
+// Not on the per-token path - the decode step uses k_gemv.h.
+//
+//   C[M,N] = epilogue( A[M,K] . op(B) )       op(B) = B^T for B [N,K] (nn.Linear weight / K-cache rows)
+//                                              op(B) = B   for B [K,N] (V rows, "NN")
+// Batched over blockIdx.z with two-level strides (batch, head).  Tile 128x128x16,
+// 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32.  Operands are staged k-major
+// in LDS so that an MFMA operand fetch (lane l needs element [k = l>>5][i = l&31])
+// is a conflict-free ds_read_b32; the next k-tile is prefetched into registers while
+// the current one is multiplied.
+#pragma once
+#include "er_common.h"
+
+namespace er {
+
+enum { GEPI_PLAIN = 0, GEPI_QKV = 1 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;        // [N] or null
+    const float* resid;       // [M][ldr] or null (added last)
+    int M, N, K;              // K % 16 == 0; A must be readable (and zero-padded) up to K
+    int lda, ldb, ldc, ldr;
+    long long sA1, sA2, sB1, sB2, sC1, sC2;   // offsets = (z / Z2) * s?1 + (z % Z2) * s?2
+    int Z2;
+    int b_is_kn;              // 0: B is [N][K]; 1: B is [K][N]
+    int kb_valid;             // NN: rows k >= kb_valid of B are treated as zero
+    float div;                // != 0: acc / div first (attention scale, as the reference divides)
+    int relu;
+    int causal;               // 1: skip tiles entirely above the diagonal (n0 > m0+127+causal_off); for NN: k beyond it
+    int causal_off;
+    int epi;                  // GEPI_*
+    // GEPI_QKV: rows m = b*S + s; cols [0,h) -> q[m][c], [h,2h) -> K cache, [2h,3h) -> V cache
+    float* q; float* kcache; float* vcache;
+    int S, hidden, head_dim, l_cap;
+    long long kv_bstride;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = GBM + 4;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    if (g.causal && !g.b_is_kn && n0 > m0 + GBM - 1 + g.causal_off) return;   // fully masked score tile
+    const int z = blockIdx.z, z1 = z / g.Z2, z2 = z - z1 * g.Z2;
+    const float* A = g.A + z1 * g.sA1 + z2 * g.sA2;
+    const float* B = g.B + z1 * g.sB1 + z2 * g.sB2;
+    float* C = g.C + z1 * g.sC1 + z2 * g.sC2;
+
+    int K = g.K;
+    if (g.causal && g.b_is_kn) {              // P.V: probabilities beyond the diagonal are exactly zero
+        const int klim = (m0 + GBM + g.causal_off + GBK - 1) / GBK * GBK;
+        K = min(K, klim);
+    }
+    const int nk = K / GBK;
+
+    // global -> register staging maps
+    const int ar = tid >> 2, akq = tid & 3;   // A / B(NT): row (0..63, +64), k-quad
+    const int bkr = tid >> 5, bnq = tid & 31; // B(NN): k row (0..7, +8), n-quad
+    f32x4 ra[2], rb[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * GBK;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int gm = m0 + ar + 64 * hh;
+            ra[hh] = (gm < g.M) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * akq) : zero4;
+        }
+        if (!g.b_is_kn) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int gn = n0 + ar + 64 * hh;
+                rb[hh] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 4 * akq) : zero4;
+            }
+        } else {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int gk = k0 + bkr + 8 * hh;
+                const int gn = n0 + 4 * bnq;
+                rb[hh] = (gk < g.kb_valid && gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gk * g.ldb + gn) : zero4;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int m = ar + 64 * hh;
+            As[(4 * akq + 0) * GLD + m] = ra[hh].x;
+            As[(4 * akq + 1) * GLD + m] = ra[hh].y;
+            As[(4 * akq + 2) * GLD + m] = ra[hh].z;
+            As[(4 * akq + 3) * GLD + m] = ra[hh].w;
+        }
+        if (!g.b_is_kn) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int n = ar + 64 * hh;
+                Bs[(4 * akq + 0) * GLD + n] = rb[hh].x;
+                Bs[(4 * akq + 1) * GLD + n] = rb[hh].y;
+                Bs[(4 * akq + 2) * GLD + n] = rb[hh].z;
+                Bs[(4 * akq + 3) * GLD + n] = rb[hh].w;
+            }
+        } else {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                *reinterpret_cast<f32x4*>(&Bs[(bkr + 8 * hh) * GLD + 4 * bnq]) = rb[hh];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+    const int kh = lane >> 5, li = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < GBK / 2; ++kk) {
+            const float* ap = As + (2 * kk + kh) * GLD + wm * 64 + li;
+            const float* bp = Bs + (2 * kk + kh) * GLD + wn * 64 + li;
+            const float a0 = ap[0], a1 = ap[32];
+            const float b0 = bp[0], b1 = bp[32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) store_tile();
+        __syncthreads();
+    }
+
+    // epilogue: C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int gn = n0 + wn * 64 + j * 32 + li;
+                if (gm >= g.M || gn >= g.N) continue;
+                float v = acc[i][j][r];
+                if (g.div != 0.f) v = v / g.div;
+                if (g.bias) v += g.bias[gn];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.resid) v += g.resid[(long long)gm * g.ldr + gn];
+                if (g.epi == GEPI_PLAIN) {
+                    C[(long long)gm * g.ldc + gn] = v;
+                } else {
+                    const int which = gn / g.hidden, c = gn - which * g.hidden;
+                    if (which == 0) {
+                        g.q[(long long)gm * g.hidden + c] = v;
+                    } else {
+                        const int b = gm / g.S, s = gm - b * g.S;
+                        const int h = c / g.head_dim, d = c - h * g.head_dim;
+                        float* cache = (which == 1) ? g.kcache : g.vcache;
+                        cache[(long long)b * g.kv_bstride + ((long long)h * g.l_cap + s) * g.head_dim + d] = v;
+                    }
+                }
+            }
+}
+
+inline GemmArgs gemm_args_default() {
+    GemmArgs g{};
+    g.Z2 = 1;
+    g.epi = GEPI_PLAIN;
+    return g;
+}
+
+inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch);
+    hipLaunchKernelGGL(gemm_f32_mfma_kernel, grid, dim3(ER_WG), 0, st, g);
+    return hipGetLastError();
+}
+
+}  // namespace er

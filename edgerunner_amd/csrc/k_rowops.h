@@ -1,0 +1,147 @@
+// Row-wise / element-wise kernels of the once-per-sample stages (prefill, point
+// encoder).  All HBM-bound streaming kernels: coalesced rows, one pass where the
+// row fits in registers.
+#pragma once
+#include "er_common.h"
+
+namespace er {
+
+// y[r,:] = LayerNorm(x[r,:]) * w + b   (nn.LayerNorm, biased variance, eps inside sqrt;
+// core/transformer/modeling_opt.py:274,288, core/transformer/point.py:137,112-114, core/models.py:65).
+// One wave per row, the row lives in registers (CPL = cols/64 values per lane).
+template <int CPL>
+__global__ __launch_bounds__(ER_WG) void layernorm_rows_kernel(const float* x, const float* w, const float* b,
+                                                               float* y, int rows, long long ldx, long long ldy,
+                                                               float eps) {
+    constexpr int COLS = CPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * ER_NWAVES + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (long long)r * ldx;
+    float v[CPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+    const float mean = wave_sum(s) / (float)COLS;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { const float d = v[i] - mean; s2 = fmaf(d, d, s2); }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)COLS + eps);
+    float* yr = y + (long long)r * ldy;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        yr[c] = (v[i] - mean) * rstd * w[c] + b[c];
+    }
+}
+
+inline hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int cols,
+                                   long long ldx, long long ldy, float eps, hipStream_t st) {
+    const int grid = (rows + ER_NWAVES - 1) / ER_NWAVES;
+    if (rows == 0) return hipSuccess;
+    switch (cols) {
+        case 1536: hipLaunchKernelGGL((layernorm_rows_kernel<24>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
+        case 1024: hipLaunchKernelGGL((layernorm_rows_kernel<16>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
+        case 512:  hipLaunchKernelGGL((layernorm_rows_kernel<8>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
+        case 256:  hipLaunchKernelGGL((layernorm_rows_kernel<4>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
+        case 64:   hipLaunchKernelGGL((layernorm_rows_kernel<1>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// In-place row softmax of attention scores (core/transformer/attention.py:53-57):
+// row r keeps columns [0, n_valid) with n_valid = causal ? min(cols, r+1+causal_off) : cols
+// (the reference adds a -inf upper triangle, whose softmax weight is exactly 0) and
+// columns [n_valid, ld_pad) are written as 0 so the following P.V GEMM may run over a
+// 16-padded K.  grid (rows, batch), one workgroup per row.
+__global__ __launch_bounds__(ER_WG) void softmax_rows_kernel(float* s, int rows, int cols, long long ld, int ld_pad,
+                                                             long long batch_stride, int causal, int causal_off) {
+    __shared__ float red[8];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    float* row = s + blockIdx.y * batch_stride + (long long)r * ld;
+    const int nv = causal ? min(cols, r + 1 + causal_off) : cols;
+    float m = -INFINITY;
+    for (int c = tid; c < nv; c += ER_WG) m = fmaxf(m, row[c]);
+    m = block_max(m, red);
+    float l = 0.f;
+    for (int c = tid; c < nv; c += ER_WG) {
+        const float e = expf(row[c] - m);
+        row[c] = e;
+        l += e;
+    }
+    l = block_sum(l, red);
+    for (int c = tid; c < nv; c += ER_WG) row[c] = row[c] / l;
+    for (int c = nv + tid; c < ld_pad; c += ER_WG) row[c] = 0.f;
+}
+
+// GEGLU (core/transformer/point.py:68-71): out[m, j] = u[m, j] * gelu_erf(u[m, F + j]).
+__global__ __launch_bounds__(ER_WG) void geglu_kernel(const float* u, float* out, long long rows, int F) {
+    const long long total = rows * F;
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
+        const long long m = i / F;
+        const int j = (int)(i - m * F);
+        const float x = u[m * 2 * F + j];
+        const float gt = u[m * 2 * F + F + j];
+        const float gelu = gt * 0.5f * (1.0f + erff(gt * 0.70710678118654752440f));
+        out[i] = x * gelu;
+    }
+}
+
+// hidden = inputs_embeds + embed_positions(arange(S))   (core/transformer/modeling_opt.py:355-357)
+__global__ __launch_bounds__(ER_WG) void add_pos_kernel(const float* emb, const float* pos, float* out, int B, int S,
+                                                        int C, int pos0) {
+    const long long total = (long long)B * S * C / 4;
+    const int c4 = C / 4;
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
+        const long long row = i / c4;
+        const int c = (int)(i - row * c4);
+        const int s = (int)(row % S);
+        const f32x4 a = reinterpret_cast<const f32x4*>(emb)[i];
+        const f32x4 p = reinterpret_cast<const f32x4*>(pos)[(long long)(pos0 + s) * c4 + c];
+        reinterpret_cast<f32x4*>(out)[i] = a + p;
+    }
+}
+
+// PointEmbed features (core/transformer/point.py:53-63): for point m,
+// out[m, 0:F) = sin(x.basis), out[m, F:2F) = cos(x.basis), out[m, 2F:2F+3) = xyz, zero-padded to ldo
+// (the 51-wide Linear input padded to a multiple of 16 for the GEMM).
+__global__ __launch_bounds__(ER_WG) void point_embed_kernel(const float* pts, const float* basis, float* out,
+                                                            long long M, int F, int ldo) {
+    const long long total = M * ldo;
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
+        const long long m = i / ldo;
+        const int c = (int)(i - m * ldo);
+        const float x = pts[m * 3 + 0], y = pts[m * 3 + 1], z = pts[m * 3 + 2];
+        float v = 0.f;
+        if (c < 2 * F) {
+            const int e = (c < F) ? c : c - F;
+            float proj = x * basis[e];
+            proj = fmaf(y, basis[F + e], proj);
+            proj = fmaf(z, basis[2 * F + e], proj);
+            v = (c < F) ? sinf(proj) : cosf(proj);
+        } else if (c < 2 * F + 3) {
+            v = pts[m * 3 + (c - 2 * F)];
+        }
+        out[i] = v;
+    }
+}
+
+// out[r, :] = table[ids[r], :]   (nn.Embedding lookups: core/models.py:137,228)
+__global__ __launch_bounds__(ER_WG) void gather_rows_kernel(const float* table, const int* ids, float* out, int rows,
+                                                            int C, long long ldo) {
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    const float* src = table + (long long)ids[r] * C;
+    float* dst = out + (long long)r * ldo;
+    for (int c = threadIdx.x; c < C; c += ER_WG) dst[c] = src[c];
+}
+
+inline int ew_grid(long long total) {
+    long long g = (total + ER_WG - 1) / ER_WG;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace er

@@ -1,0 +1,93 @@
+"""Torch-tensor wrappers over the single-kernel C-ABI entry points (``er_k_*``).
+Used by the GPU unit tests and for debugging; the product path goes through
+``NativeShapeOPT`` / ``er_decode``."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import native
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemv(w, x, bias=None, ln_w=None, ln_b=None, resid=None, relu=False, eps=1e-5, return_xnorm=False):
+    """y[b,n] = act(W x_b + bias) (+resid); LayerNorm(x) first when ln_w is given."""
+    lib = native.load_library()
+    B, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    xn = torch.empty_like(x) if return_xnorm else None
+    native.check(lib.er_k_gemv(native.ptr(w), native.ptr(bias), native.ptr(x), native.ptr(ln_w), native.ptr(ln_b),
+                               native.ptr(resid), native.ptr(y), native.ptr(xn), B, N, K, int(relu), float(eps), _st()),
+                 "er_k_gemv")
+    return (y, xn) if return_xnorm else y
+
+
+def attn_decode(q, k_cache, v_cache, lens, splits=48):
+    """q [B,H*D]; caches [B,H,Lcap,D]; lens: list[int] -> out [B,H*D]."""
+    lib = native.load_library()
+    B, H, Lcap, D = k_cache.shape
+    out = torch.empty((B, H * D), dtype=torch.float32, device=q.device)
+    native.check(lib.er_k_attn_decode(native.ptr(q), native.ptr(k_cache), native.ptr(v_cache), native.i32_array(lens),
+                                      native.ptr(out), B, H, D, Lcap, splits, _st()), "er_k_attn_decode")
+    return out
+
+
+def gemm(a, b, bias=None, resid=None, b_is_kn=False, relu=False, div=0.0, m=None, n=None, k=None):
+    """C = A.op(B) with row strides taken from the (2-D, row-contiguous) tensors."""
+    lib = native.load_library()
+    M = a.shape[0] if m is None else m
+    K = a.shape[1] if k is None else k
+    N = (b.shape[1] if b_is_kn else b.shape[0]) if n is None else n
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    native.check(lib.er_k_gemm(native.ptr(a), native.ptr(b), native.ptr(bias), native.ptr(resid), native.ptr(c), M, N, K,
+                               a.stride(0), b.stride(0), c.stride(0), int(b_is_kn), int(relu), float(div), _st()),
+                 "er_k_gemm")
+    return c
+
+
+def layernorm(x, w, b, eps=1e-5):
+    lib = native.load_library()
+    y = torch.empty_like(x)
+    native.check(lib.er_k_layernorm(native.ptr(x), native.ptr(w), native.ptr(b), native.ptr(y), x.shape[0], x.shape[1],
+                                    float(eps), _st()), "er_k_layernorm")
+    return y
+
+
+def softmax_(s, cols, causal=False):
+    """In place over s [rows, ld]: softmax of the first `cols` (or row+1 if causal) columns, zeros after."""
+    lib = native.load_library()
+    native.check(lib.er_k_softmax(native.ptr(s), s.shape[0], cols, s.stride(0), int(causal), _st()), "er_k_softmax")
+    return s
+
+
+def sample_head(logits, mode, grammar, step, last_tok, counter, unfinished, top_k=10, min_new=0, seed=0,
+                eos=2, pad=0):
+    """One sampling-head step. Returns (next_tok, counter, unfinished) lists."""
+    lib = native.load_library()
+    B, V = logits.shape
+    p = native.ErDecodeParams(mode=mode, top_k=top_k, grammar=grammar, max_new_tokens=step + 1,
+                              min_new_tokens=min_new, seed=seed)
+    nt, co, uo = (C.c_int32 * B)(), (C.c_int32 * B)(), (C.c_int32 * B)()
+    native.check(lib.er_k_sample_head(native.ptr(logits), C.byref(p), V, eos, pad, B, step, native.i32_array(last_tok),
+                                      native.i32_array(counter), native.i32_array(unfinished), nt, co, uo, _st()),
+                 "er_k_sample_head")
+    return list(nt), list(co), list(uo)
+
+
+def philox_uniform(seed: int, step: int, row: int) -> float:
+    """Host replica of the device sampler's uniform draw (Philox4x32-10, key = seed,
+    counter = (step, row, 0, 0), u = (x0 >> 8) * 2^-24)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [step & 0xFFFFFFFF, row & 0xFFFFFFFF, 0, 0]
+    k = [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF,
+             p0 & 0xFFFFFFFF]
+        k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+    return float(c[0] >> 8) / 16777216.0

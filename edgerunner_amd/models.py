@@ -1,0 +1,133 @@
+"""``LMM`` - drop-in for the reference's ``core.models.LMM`` on the ArAE decode path
+(reference: core/models.py:32-99 constructor, :101-144 encode_cond, :204-319 generate).
+
+Same constructor argument (``Options``), same checkpoint keys, same
+``generate(conds, num_faces, resume_ids, tokenizer, max_new_tokens, clean)``
+signature and return value ``(meshes, all_tokens)``.  Differences, all additive:
+``B > 1`` is allowed (independent rows, per-row grammar state), ``min_new_tokens``
+can be passed (benchmark rule: EOS suppressed until T), and training-only members
+(``forward``, image conditioner) are not part of this path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import native
+from .grammar import select_grammar
+from .shape_opt import BuiltinGrammar, NativeShapeOPT
+from .utils import quantize_num_faces
+from .weights import dims_from_options
+
+
+class _Embd:
+    """``mesh_decoder.model.embd`` lookalike (core/models.py:228)."""
+
+    def __init__(self, dec: NativeShapeOPT):
+        self._dec = dec
+
+    def __call__(self, input_ids):
+        return self._dec.embd(input_ids)
+
+
+class _DecoderModel:
+    def __init__(self, dec):
+        self.embd = _Embd(dec)
+
+
+class LMM:
+    def __init__(self, opt, device="cuda:0"):
+        self.opt = opt
+        if opt.cond_mode == "image":
+            raise NotImplementedError("cond_mode='image' (CLIP conditioner) is outside the ArAE decode path")
+        if opt.cond_mode == "point" and opt.point_encoder_mode != "embed":
+            raise NotImplementedError("point_encoder_mode='downsample' needs torch_cluster FPS; ArAE uses 'embed'")
+        self.dims = dims_from_options(opt)
+        self.vocab_size = self.dims.vocab_size
+        self.device = torch.device(device)
+        self.mesh_decoder = NativeShapeOPT(self.dims, opt, self.device)
+        self.mesh_decoder.model = _DecoderModel(self.mesh_decoder)
+        self.training = False
+        self._dtype_requested = torch.float32
+
+    # -- nn.Module-shaped conveniences so infer.py reads like the reference's ----------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        return self.mesh_decoder.load_state_dict(sd, strict=strict)
+
+    def half(self):
+        # The reference casts to fp16 here (infer.py:56).  This round builds the exact fp32
+        # streaming mode only (bit-exact greedy parity with the CPU path); the request is recorded.
+        self._dtype_requested = torch.float16
+        return self
+
+    def float(self):
+        self._dtype_requested = torch.float32
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise native.NativeError("this LMM only runs on a HIP device")
+        return self
+
+    # -- conditioning -------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_cond(self, conds, num_faces):
+        """core/models.py:101-144 (eval mode).  ``num_faces``: LongTensor[B] or list."""
+        nf = num_faces.tolist() if isinstance(num_faces, torch.Tensor) else list(num_faces)
+        buckets = [quantize_num_faces(int(n)) for n in nf]
+        return {"cond_embeds": self.mesh_decoder.encode_cond(conds, buckets)}
+
+    # -- generation ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_ids(self, conds, num_faces=1000, resume_ids=None, tokenizer=None, max_new_tokens=None,
+                     min_new_tokens: int = 0, seed: Optional[int] = None) -> torch.Tensor:
+        """Everything of LMM.generate up to the HF call's return value (core/models.py:215-303)."""
+        opt = self.opt
+        B = conds.shape[0]
+        cond_embeds = self.encode_cond(conds, [num_faces] * B)["cond_embeds"]
+        input_ids = torch.full((B, 1), opt.bos_token_id, dtype=torch.long)
+        if resume_ids is not None:
+            input_ids = torch.cat((input_ids, resume_ids.to("cpu", torch.long)), dim=1)
+        tokens_embeds = self.mesh_decoder.model.embd(input_ids)
+        inputs_embeds = torch.cat((cond_embeds, tokens_embeds), dim=1) if cond_embeds is not None else tokens_embeds
+        fn = BuiltinGrammar(select_grammar(opt, tokenizer is not None), self.vocab_size, opt.eos_token_id)
+        if fn.er_grammar == native.ER_GRAMMAR_NONE:
+            print("[WARN] prefix_allowed_tokens_fn is not defined for meto backend:", opt.meto_backend)
+            fn = None
+        max_new_tokens = opt.max_seq_length if max_new_tokens is None else max_new_tokens
+        if num_faces < 0:
+            num_tokens = torch.full((B,), -1, dtype=torch.long)
+        else:
+            num_tokens = torch.full((B,), num_faces * 4 + opt.num_cond_tokens, dtype=torch.long)
+        kwargs = dict(inputs_embeds=inputs_embeds, num_tokens=num_tokens, pad_token_id=opt.pad_token_id,
+                      bos_token_id=opt.bos_token_id, eos_token_id=opt.eos_token_id, max_new_tokens=max_new_tokens,
+                      prefix_allowed_tokens_fn=fn, min_new_tokens=min_new_tokens, seed=seed)
+        if opt.generate_mode == "greedy":
+            kwargs["num_beams"] = 1
+        elif opt.generate_mode == "sample":
+            kwargs["do_sample"] = True
+            kwargs["top_k"] = 10
+        return self.mesh_decoder.generate(**kwargs)
+
+    @torch.no_grad()
+    def generate(self, conds, num_faces=1000, resume_ids=None, tokenizer=None, max_new_tokens=None, clean=True,
+                 min_new_tokens: int = 0, seed: Optional[int] = None):
+        """-> (meshes, all_tokens) like core/models.py:204-319.  Detokenisation
+        (save_mesh -> meto decode -> trimesh, core/provider.py:39-66) is the "next" row
+        of the scope table; until it lands ``meshes`` holds ``None`` placeholders."""
+        output_ids = self.generate_ids(conds, num_faces, resume_ids, tokenizer, max_new_tokens, min_new_tokens, seed)
+        meshes: List[Optional[object]] = []
+        all_tokens: List[np.ndarray] = []
+        out = output_ids.detach().cpu().numpy()
+        for b in range(out.shape[0]):
+            tokens = out[b]
+            if resume_ids is not None:
+                tokens = np.concatenate((resume_ids[b].detach().cpu().numpy(), tokens), axis=0)
+            meshes.append(None)
+            all_tokens.append(tokens)
+        return meshes, all_tokens

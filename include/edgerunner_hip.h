@@ -1,0 +1,177 @@
+/*
+ * edgerunner_hip.h - C ABI of the MI355X-native (gfx950) ArAE decode path.
+ *
+ * The reference (NVlabs/EdgeRunner) has no plugin/FFI layer on this path; the
+ * seam this library replaces is the call
+ *     output_ids = self.mesh_decoder.generate(**kwargs)      core/models.py:303
+ * (kwargs built at core/models.py:286-301) together with the arithmetic above
+ * and below it inside LMM.generate:
+ *     encode_cond          core/models.py:101-144  (+ core/transformer/point.py:172-206)
+ *     embd(input_ids)      core/models.py:228      (core/transformer/modeling_opt.py:313)
+ *     ShapeOPT.forward     core/transformer/modeling_opt.py:464-517 (prefill + cached steps)
+ *     logits processors    core/utils.py:118-141, core/models.py:236-275 (grammar)
+ *     greedy / top-k=10 sampling, EOS/pad bookkeeping  (transformers 4.46.2 _sample)
+ *
+ * Conventions
+ *   - plain C types only; every "dev" pointer is a device (HBM) pointer owned by
+ *     the caller (e.g. torch-ROCm tensor.data_ptr()), every "host" pointer is
+ *     ordinary host memory;
+ *   - every function returns 0 on success, a negative er_status otherwise; the
+ *     message is retrievable with er_last_error() (thread-local);
+ *   - no C++ exception crosses the ABI;
+ *   - all device work is enqueued on the caller-supplied hipStream_t (passed as
+ *     void*; NULL = the default stream).  A context is bound to one device and
+ *     is not thread-safe; different contexts are independent;
+ *   - weights, KV cache and workspaces are context-owned (hipMalloc).
+ */
+#ifndef EDGERUNNER_HIP_H
+#define EDGERUNNER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ER_ABI_VERSION 1
+
+typedef enum {
+    ER_OK = 0,
+    ER_ERR_INVALID = -1,      /* bad argument / shape / state        */
+    ER_ERR_HIP = -2,          /* a HIP runtime call failed           */
+    ER_ERR_MISSING = -3,      /* a required tensor was never loaded  */
+    ER_ERR_CAPACITY = -4,     /* KV cache / position table too small */
+    ER_ERR_UNSUPPORTED = -5   /* configuration not built             */
+} er_status;
+
+typedef enum { ER_F32 = 0, ER_F16 = 1, ER_BF16 = 2 } er_dtype;
+typedef enum { ER_COND_NONE = 0, ER_COND_POINT = 1, ER_COND_POINT_LATENT = 2 } er_cond_mode;
+typedef enum { ER_GREEDY = 0, ER_SAMPLE = 1 } er_gen_mode;
+/* prefix_allowed_tokens_fn variants LMM.generate can build (core/models.py:236-275) */
+typedef enum {
+    ER_GRAMMAR_NONE = 0,      /* prefix_allowed_tokens_fn = None                            */
+    ER_GRAMMAR_NAIVE9 = 1,    /* tokenizer is None: ids >= 3, EOS iff len % 9 == 1  (:237-242) */
+    ER_GRAMMAR_LR_ABSCO = 2   /* meto LR / LR_ABSCO counter automaton               (:246-271) */
+} er_grammar;
+
+/* Model description: mirrors ShapeOPTConfig (core/transformer/modeling_opt.py:86-134)
+ * and the Options fields LMM.__init__ reads (core/models.py:32-99). */
+typedef struct {
+    int32_t hidden_dim, num_heads, num_layers, intermediate_dim;
+    int32_t vocab_size, max_positions, num_cond_tokens;
+    int32_t point_hidden_dim, point_num_heads, point_latent_size, point_latent_dim;
+    int32_t point_freq_dim;      /* columns of point_embed.basis (24)          */
+    int32_t num_face_buckets;    /* rows of embed_num_face (10); 0 = no face cond */
+    int32_t cond_mode;           /* er_cond_mode                               */
+    int32_t pad_token_id, bos_token_id, eos_token_id;
+    int32_t weight_dtype;        /* er_dtype the decoder weights are streamed in */
+    int32_t kv_dtype;            /* er_dtype of the KV cache                    */
+    float   ln_eps;              /* 1e-5 (nn.LayerNorm default)                 */
+} er_config;
+
+/* kwargs of mesh_decoder.generate (core/models.py:286-301) that are not tensors. */
+typedef struct {
+    int32_t mode;                /* er_gen_mode: num_beams=1 | do_sample=True     */
+    int32_t top_k;               /* 10 in the reference (sample mode only)         */
+    int32_t grammar;             /* er_grammar                                    */
+    int32_t max_new_tokens;
+    int32_t min_new_tokens;      /* HF MinNewTokensLength semantics; 0 = off      */
+    uint64_t seed;               /* Philox key of the device sampler              */
+} er_decode_params;
+
+typedef struct er_ctx er_ctx;
+
+int         er_abi_version(void);
+const char* er_last_error(void);
+
+int er_create(const er_config* cfg, int device, er_ctx** out);
+int er_destroy(er_ctx* ctx);
+
+/* Checkpoint loading: one call per state_dict entry, keyed by the reference's own
+ * key names (replaces model.load_state_dict, infer.py:44-50).
+ * `data` is host (on_device=0) or device (on_device=1) memory, contiguous,
+ * row-major.  Unknown keys are ignored (strict=False) and reported via return
+ * value 1.  The tensor is converted to the context's storage dtype and repacked
+ * (q/k/v fused per layer). */
+int er_load_tensor(er_ctx* ctx, const char* key, const void* data, int dtype,
+                   int ndim, const int64_t* shape, int on_device);
+/* Verifies every required tensor was provided (ER_ERR_MISSING names the first gap). */
+int er_finalize_weights(er_ctx* ctx);
+
+/* Pre-allocates the context-owned KV cache for `batch` sequences of up to
+ * `max_len` positions (prefix + generated).  Replaces the per-step torch.cat
+ * growth of core/transformer/modeling_opt.py:191-192. */
+int er_kv_reserve(er_ctx* ctx, int batch, int max_len);
+
+/* encode_cond (core/models.py:101-144), eval mode.
+ *   cond_mode POINT:        conds_dev = float[B, N, 3] point clouds
+ *   cond_mode POINT_LATENT: conds_dev = float[B, point_latent_size, point_latent_dim], n_points ignored
+ *   cond_mode NONE:         conds_dev ignored
+ * face_bucket_host = int[B] = quantize_num_faces(num_faces) (core/utils.py:89-116), ignored when
+ * num_face_buckets == 0.  cond_out_dev = float[B, num_cond_tokens, hidden_dim]. */
+int er_encode_cond(er_ctx* ctx, const float* conds_dev, int batch, int n_points,
+                   const int32_t* face_bucket_host, float* cond_out_dev, void* stream);
+
+/* mesh_decoder.model.embd(input_ids) (core/models.py:228): ids_host int[B*R] -> float[B, R, hidden]. */
+int er_embed_tokens(er_ctx* ctx, const int32_t* ids_host, int batch, int n_tokens,
+                    float* out_dev, void* stream);
+
+/* First generation step of ShapeOPT (prepare_inputs_for_generation step 0,
+ * core/transformer/modeling_opt.py:536-538): runs all layers over
+ * inputs_embeds float[B, S, hidden], fills KV positions [0, S) and leaves the
+ * hidden state of the last position ready for er_logits / er_decode. */
+int er_prefill(er_ctx* ctx, const float* embeds_dev, int batch, int seq_len, void* stream);
+
+/* logits[:, -1, :].float() of the most recent forward (prefill or er_feed): float[B, vocab]. */
+int er_logits(er_ctx* ctx, float* logits_out_dev, void* stream);
+
+/* One cached decode step with caller-chosen ids (teacher forcing / host-side
+ * logits processors): ShapeOPT(input_ids=ids[:, None], past_key_values=...). */
+int er_feed(er_ctx* ctx, const int32_t* ids_host, void* stream);
+
+/* The whole generation loop on device (no host round trip per token): replaces
+ * GenerationMixin._sample for the reference's kwargs.  out_ids_dev = int64[B, max_new_tokens]
+ * (rows padded with pad_token_id after EOS, as HF does); *n_steps_host = number of
+ * columns HF would have returned (stops when every row has emitted EOS).
+ * Blocks until the result is complete. */
+int er_decode(er_ctx* ctx, const er_decode_params* p, int64_t* out_ids_dev,
+              int32_t* n_steps_host, void* stream);
+
+/* ---- measurement ---- */
+#define ER_NUM_KERNEL_KINDS 8
+/* kinds: 0 qkv_gemv 1 attn_decode 2 attn_combine 3 out_proj_gemv 4 fc1_gemv 5 fc2_gemv 6 lm_head_gemv 7 sample_head */
+const char* er_kernel_kind_name(int kind);
+/* Times each decode kernel kind in place (HIP events on `stream`, eager launches
+ * sweeping all layers so weights are not cache-resident): avg_us_out[kind] =
+ * average duration of ONE launch, bytes_out[kind] = algorithmic HBM bytes of one
+ * launch at the current context length.  Does not advance the generation state. */
+int er_profile_decode_kernels(er_ctx* ctx, int repeats, float* avg_us_out, double* bytes_out, void* stream);
+/* Milliseconds spent inside the last er_decode between its first and last step (HIP events). */
+int er_last_decode_ms(er_ctx* ctx, float* ms_out);
+
+/* ---- single-kernel entry points (unit tests call these through the ABI) ---- */
+/* y[b,n] = act(sum_k W[n,k] x[b,k] + bias[n]) (+resid) ; ln_w != NULL -> x = LayerNorm(x) first */
+int er_k_gemv(const float* w_dev, const float* bias_dev, const float* x_dev, const float* ln_w_dev,
+              const float* ln_b_dev, const float* resid_dev, float* y_dev, float* xnorm_out_dev,
+              int batch, int n, int k, int relu, float eps, void* stream);
+/* softmax(q K^T / sqrt(D)) V for one new token over a [B,H,Lcap,D] cache holding len[b] keys */
+int er_k_attn_decode(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* len_host,
+                     float* out_dev, int batch, int heads, int head_dim, int l_cap, int splits, void* stream);
+/* C[M,N] = A[M,K] op(B) (+bias)(relu)(+resid); b_is_kn=0: B is [N,K] (Linear weight), 1: B is [K,N] */
+int er_k_gemm(const float* a_dev, const float* b_dev, const float* bias_dev, const float* resid_dev,
+              float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int b_is_kn, int relu,
+              float div, void* stream);
+int er_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
+                   int rows, int cols, float eps, void* stream);
+/* rows of scores[rows, ld]: softmax over the first n_valid(row) columns (causal: row+1+causal_offset), zeros after */
+int er_k_softmax(float* s_dev, int rows, int cols, int ld, int causal, void* stream);
+/* one sampling-head step on given logits float[B,V]; state arrays are int[B] on device */
+int er_k_sample_head(const float* logits_dev, const er_decode_params* p, int vocab, int eos, int pad,
+                     int batch, int step, const int32_t* last_tok_host, const int32_t* counter_host,
+                     const int32_t* unfinished_host, int32_t* next_tok_host, int32_t* counter_out_host,
+                     int32_t* unfinished_out_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDGERUNNER_HIP_H */

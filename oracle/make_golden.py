@@ -1,0 +1,262 @@
+"""TEST INFRASTRUCTURE ONLY.  Build-container script (needs /root/reference).
+
+1. Validates ``oracle/arae_oracle.py`` against the reference's OWN modules
+   (imported unmodified from /root/reference via ``ref_stubs``): encode_cond,
+   prefill logits and cached decode-step logits must be ``torch.equal``.
+2. Generates the golden fixtures under ``tests/golden/`` by running the
+   reference's modules (``LMM.encode_cond``, ``ShapeOPT.forward`` with the legacy
+   tuple cache) under the restated HuggingFace loop (see arae_oracle.generate).
+
+Usage:  python oracle/make_golden.py small|eos  # ~1 min each
+        python oracle/make_golden.py full       # ~10 min (24 layers, T=4000)
+Fixtures are small .npz files; the weights are regenerated from the seed by
+``edgerunner_amd.weights`` (never committed).
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_stubs  # noqa: E402
+
+ref_stubs.install()
+from core.options import config_defaults as ref_config_defaults  # noqa: E402  (reference)
+from core.models import LMM as RefLMM  # noqa: E402  (reference)
+
+import arae_oracle as O  # noqa: E402
+from edgerunner_amd import weights as W  # noqa: E402
+from edgerunner_amd.options import config_defaults  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 0
+WEIGHT_STYLE = "perturbed"
+
+
+def build_reference(ref_opt, sd):
+    model = RefLMM(ref_opt)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return model.float().eval()
+
+
+def ref_forward(model):
+    def fwd(input_ids=None, inputs_embeds=None, past=None):
+        out = model.mesh_decoder(input_ids=input_ids, inputs_embeds=inputs_embeds,
+                                 past_key_values=past, use_cache=True)
+        return out.logits, out.past_key_values
+    return fwd
+
+
+def ref_encode(model):
+    def enc(conds, nf):
+        return model.encode_cond(conds, nf)["cond_embeds"]
+    return enc
+
+
+def opts(num_layers, **kw):
+    mine = dataclasses.replace(config_defaults["ArAE"], num_layers=num_layers, checkpointing=False, **kw)
+    ref = dataclasses.replace(ref_config_defaults["ArAE"], num_layers=num_layers, checkpointing=False, **kw)
+    return mine, ref
+
+
+def weight_fingerprints(sd):
+    keys = ["mesh_decoder.lm_head.weight", "mesh_decoder.model.layers.0.fc1.weight",
+            "mesh_decoder.model.layers.0.fc1.bias", "mesh_decoder.model.embed_positions.weight",
+            "proj_cond.weight", "point_encoder.query_embed", "point_encoder.cross_att.mlp.net.0.weight",
+            "mesh_decoder.model.layers.0.final_layer_norm.weight"]
+    return {k: list(W.fingerprint(sd[k])) for k in keys if k in sd}
+
+
+COND_ROWS = [0, 1, 777, 2047, 2048]
+
+
+@torch.no_grad()
+def validate_restatement(model, sd, opt, conds):
+    """arae_oracle vs the reference's own modules: must be bit-identical."""
+    nf = torch.full((conds.shape[0],), 1000, dtype=torch.long)
+    c_ref = model.encode_cond(conds, nf)["cond_embeds"]
+    c_mine = O.encode_cond(sd, opt, conds, nf)
+    ok = torch.equal(c_ref, c_mine)
+    bos = torch.full((conds.shape[0], 1), opt.bos_token_id, dtype=torch.long)
+    emb = torch.cat((c_ref, model.mesh_decoder.model.embd(bos)), dim=1)
+    fr, fm = ref_forward(model), O.make_forward(sd, opt)
+    lr, pr = fr(inputs_embeds=emb)
+    lm, pm = fm(inputs_embeds=emb)
+    ok &= torch.equal(lr, lm)
+    for tok in (5, 100, 517, 3):
+        ids = torch.full((conds.shape[0], 1), tok, dtype=torch.long)
+        lr, pr = fr(input_ids=ids, past=pr)
+        lm, pm = fm(input_ids=ids, past=pm)
+        ok &= torch.equal(lr, lm)
+    ok &= all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(pr, pm))
+    return bool(ok)
+
+
+def run_case(model, sd, opt, conds, num_faces, T, min_new, *, use_tokenizer=True, resume_ids=None,
+             n_logits=0, check_restatement=True):
+    """ids (+ first n_logits step logits) from the reference modules under the restated HF loop."""
+    rec = {}
+
+    def record(t, s):
+        if t < n_logits:
+            rec[t] = s.numpy().copy()
+
+    ids = O.lmm_generate_ids(sd, opt, conds, num_faces, resume_ids=resume_ids, use_tokenizer=use_tokenizer,
+                             max_new_tokens=T, min_new_tokens=min_new, fwd=ref_forward(model),
+                             encode_fn=ref_encode(model), record_logits=record)
+    if check_restatement:
+        ids2 = O.lmm_generate_ids(sd, opt, conds, num_faces, resume_ids=resume_ids,
+                                  use_tokenizer=use_tokenizer, max_new_tokens=T, min_new_tokens=min_new)
+        assert torch.equal(ids, ids2), "restatement diverged from reference modules"
+    logits = np.stack([rec[t] for t in sorted(rec)]) if rec else np.zeros((0,), np.float32)
+    return ids.numpy(), logits
+
+
+def manifest_update(entry_name, entry):
+    path = os.path.join(GOLD, "MANIFEST.json")
+    m = json.load(open(path)) if os.path.exists(path) else {}
+    m[entry_name] = entry
+    m["_env"] = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads(),
+                 "weight_seed": WEIGHT_SEED, "weight_style": WEIGHT_STYLE,
+                 "reference": "NVlabs/EdgeRunner @ 2024-12-20 (/root/reference), modules imported unmodified",
+                 "loop": "restated transformers==4.46.2 _sample (oracle/arae_oracle.py::generate)"}
+    json.dump(m, open(path, "w"), indent=1, sort_keys=True)
+
+
+@torch.no_grad()
+def make_small():
+    """ArAE widths (1536/16 heads/6144, encoder 1024) with 2 decoder layers."""
+    opt, ref_opt = opts(2, generate_mode="greedy")
+    sd = W.make_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE)
+    model = build_reference(ref_opt, sd)
+    pc0 = W.synthetic_point_cloud(0, 4096)
+    pc1 = W.synthetic_point_cloud(1, 1000)      # ragged / non-multiple-of-anything point count
+    bit_identical = validate_restatement(model, sd, opt, pc0)
+    bit_identical &= validate_restatement(model, sd, opt, torch.cat([pc0, W.synthetic_point_cloud(2, 4096)]))
+    print("restatement bit-identical to reference modules:", bit_identical)
+    assert bit_identical
+
+    out = {}
+    nf = torch.full((1,), 1000, dtype=torch.long)
+    cond0 = model.encode_cond(pc0, nf)["cond_embeds"]
+    out["cond0_rows"] = cond0[0, COND_ROWS].numpy()
+    out["cond0_sum"] = np.array([float(cond0.double().sum()), float(cond0.double().abs().sum())])
+    cond1 = model.encode_cond(pc1, torch.full((1,), 4000, dtype=torch.long))["cond_embeds"]
+    out["cond1_rows"] = cond1[0, COND_ROWS].numpy()
+
+    # (a) greedy, natural EOS (random-init emits EOS early under the grammar)
+    out["ids_natural"], _ = run_case(model, sd, opt, pc0, 1000, 256, 0)
+    # (b) greedy, EOS suppressed until T (benchmark rule), with per-step logits
+    out["ids_min96"], out["logits_min96"] = run_case(model, sd, opt, pc0, 1000, 96, 96, n_logits=96)
+    # (c) other cloud / face bucket / ragged point count
+    out["ids_pc1_f4000"], out["logits_pc1_f4000"] = run_case(model, sd, opt, pc1, 4000, 48, 48, n_logits=8)
+    # (d) no-tokenizer grammar (EOS only at len % 9 == 1)
+    out["ids_notok"], _ = run_case(model, sd, opt, pc0, 1000, 40, 0, use_tokenizer=False)
+    # (e) resume_ids continuation (core/models.py:225-226)
+    resume = torch.tensor([[5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 3, 20, 21, 22]], dtype=torch.long)
+    out["resume_ids"] = resume.numpy()
+    out["ids_resume"], out["logits_resume"] = run_case(model, sd, opt, pc0, 1000, 32, 32, resume_ids=resume, n_logits=4)
+    # (f) unconditional face count (num_faces <= 0 -> bucket 0)
+    out["ids_f0"], _ = run_case(model, sd, opt, pc0, -1, 24, 24)
+
+    # (g) point_latent mode (infer_dit.py:55: latents [1,2048,64] instead of points)
+    opt_l, ref_l = opts(2, generate_mode="greedy", cond_mode="point_latent")
+    sd_l = {k: v for k, v in sd.items() if not k.startswith("point_encoder.")}
+    model_l = build_reference(ref_l, sd_l)
+    g = torch.Generator().manual_seed(77)
+    lat = torch.randn(1, 2048, 64, generator=g)
+    out["latents_seed"] = np.array([77])
+    out["ids_latent"], out["logits_latent"] = run_case(model_l, sd_l, opt_l, lat, 2000, 32, 32, n_logits=4)
+
+    np.savez_compressed(os.path.join(GOLD, "arae_small.npz"), **out)
+    manifest_update("arae_small", {
+        "num_layers": 2, "restatement_bit_identical": bool(bit_identical),
+        "weight_fingerprints": weight_fingerprints(sd), "cond_rows": COND_ROWS,
+        "cases": {k: list(v.shape) for k, v in out.items()},
+    })
+    print({k: v.shape for k, v in out.items()})
+    print("natural EOS length:", out["ids_natural"].shape, out["ids_natural"][0][:20])
+
+
+@torch.no_grad()
+def make_eos():
+    """Natural-EOS cases with different stop steps (reference-style init, seed 2,
+    4 layers, 512-point clouds 0/1/3 stop at steps 94/38/10)."""
+    opt, ref_opt = opts(4, generate_mode="greedy")
+    sd = W.make_state_dict(opt, 2, "reference")
+    model = build_reference(ref_opt, sd)
+    out = {"clouds": np.array([0, 1, 3]), "num_points": np.array([512])}
+    for i in (0, 1, 3):
+        pc = W.synthetic_point_cloud(i, 512)
+        out[f"ids_c{i}"], out[f"logits_c{i}"] = run_case(model, sd, opt, pc, 1000, 160, 0, n_logits=4)
+        print(i, out[f"ids_c{i}"].shape)
+    np.savez_compressed(os.path.join(GOLD, "arae_eos.npz"), **out)
+    manifest_update("arae_eos", {"num_layers": 4, "weight_seed": 2, "weight_style": "reference",
+                                 "weight_fingerprints": weight_fingerprints(sd),
+                                 "cases": {k: list(v.shape) for k, v in out.items()}})
+
+
+@torch.no_grad()
+def make_full(T=4000):
+    """BASELINE configs[0]/[1]: ArAE 24 layers, cloud 0 (4096 pts), greedy,
+    test_num_face=1000, T=4000 new tokens with EOS suppressed until T."""
+    opt, ref_opt = opts(24, generate_mode="greedy")
+    t0 = time.time()
+    sd = W.make_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE)
+    model = build_reference(ref_opt, sd)
+    print(f"built in {time.time() - t0:.1f}s")
+    pc0 = W.synthetic_point_cloud(0, 4096)
+    keep = set(range(64)) | set(range(0, T, 256)) | {T - 1}
+    rec, times = {}, []
+
+    def record(t, s):
+        if t in keep:
+            rec[t] = s.numpy().copy()
+
+    def timer(t):
+        times.append(time.perf_counter())
+        if t % 500 == 0:
+            print("step", t, f"{time.time() - t0:.0f}s", flush=True)
+
+    t1 = time.perf_counter()
+    ids = O.lmm_generate_ids(sd, opt, pc0, 1000, max_new_tokens=T, min_new_tokens=T,
+                             fwd=ref_forward(model), encode_fn=ref_encode(model),
+                             record_logits=record, step_timer=timer)
+    t2 = time.perf_counter()
+    steps = sorted(rec)
+    top2 = []
+    np.savez_compressed(os.path.join(GOLD, f"arae_full_T{T}.npz"), ids=ids.numpy(),
+                        logit_steps=np.array(steps), logits=np.stack([rec[s] for s in steps]))
+    dt = np.diff(np.array(times))
+    manifest_update(f"arae_full_T{T}", {
+        "num_layers": 24, "T": T, "weight_fingerprints": weight_fingerprints(sd),
+        "cpu_seconds_total": t2 - t1, "cpu_threads": torch.get_num_threads(),
+        "cpu_decode_tok_per_s": float(len(dt) / dt.sum()),
+        "cpu_ms_per_token_first100": float(dt[:100].mean() * 1e3),
+        "cpu_ms_per_token_last100": float(dt[-100:].mean() * 1e3),
+    })
+    print("done", ids.shape, f"{t2 - t1:.0f}s; decode tok/s {len(dt) / dt.sum():.2f}")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if what == "small":
+        make_small()
+    elif what == "eos":
+        make_eos()
+    elif what == "full":
+        make_full(int(sys.argv[2]) if len(sys.argv) > 2 else 4000)
+    else:
+        raise SystemExit(__doc__)
