@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Benchmark of the ArAE decode hot path on MI355X (contract: see the task's bench.py section).
+
+One "step" = one full pass of the hot path for one synthetic point cloud per GPU:
+encode_cond (point encoder) -> 2050-token prefill -> T greedy tokens with the device-side
+grammar head (LMM.generate; reference core/models.py:204-303).  Workload = BASELINE.json
+configs[1]: ArAE (24 layers, 1536 wide) random-init, batch 1, greedy, test_num_face=1000,
+T = 4*num_faces = 4000 new tokens with EOS suppressed until T, 4096-point cloud, exact fp32
+mode (the mode whose greedy ids are bit-exact vs the reference CPU path).
+
+N > 1: one process per GPU (torchrun), every rank generates for its own cloud (weak
+scaling: independent samples, full weight replica per GPU, no data-path collective) and the
+token streams are all-gathered once per step over RCCL.  value = total tokens / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
+W_ELEMS = 680_752_128          # streamed weight elements per token
+KV_ELEMS_PER_POS = 73_728      # 2 * 24 * 1536
+LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "out_proj_gemv": 24, "fc1_gemv": 24,
+                      "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
+
+
+def cpu_baseline(opt, sd, T_sample, num_points):
+    """Reference CPU-eager path timed on this box's host cores: the oracle (a torch-CPU fp32
+    restatement that is bit-identical to the reference's own modules, see oracle/) on a bounded
+    sample of the same workload: encode + prefill + the first T_sample decode steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import arae_oracle as O
+    from edgerunner_amd import weights as W
+    torch.set_num_threads(os.cpu_count() or 1)
+    pc = W.synthetic_point_cloud(0, num_points)
+    marks = []
+    t0 = time.perf_counter()
+    O.lmm_generate_ids(sd, opt, pc, 1000, max_new_tokens=T_sample, min_new_tokens=T_sample,
+                       step_timer=lambda t: marks.append(time.perf_counter()))
+    t1 = time.perf_counter()
+    dec = np.diff(np.array(marks))
+    return {
+        "value": round(float(len(dec) / dec.sum()), 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle (torch CPU fp32, = reference modules bit-for-bit): encode_cond + 2050-token prefill "
+                  f"({marks[0] - t0:.1f}s) + first {T_sample} greedy decode steps at context 2050..{2050 + T_sample} "
+                  f"({dec.sum():.1f}s); the full run would be slower per token as context grows to 6050",
+        "end_to_end_tokens_per_s_on_sample": round(T_sample / (t1 - t0), 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--num-face", type=int, default=1000)
+    ap.add_argument("--tokens", type=int, default=None, help="new tokens per sample (default 4*num_face)")
+    ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=120, help="decode steps of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    from edgerunner_amd import dist as D
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models import LMM
+    from edgerunner_amd.options import config_defaults
+
+    rank, world, local = D.init_process_group()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    T = args.tokens or 4 * args.num_face
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=args.layers, generate_mode="greedy")
+
+    t0 = time.time()
+    lmm = LMM(opt, dev)
+    keep_sd = rank == 0 and world == 1 and args.cpu_steps > 0
+    sd = {}
+    def items():
+        for k, t in W.iter_state_dict(opt, 0, "perturbed"):
+            if keep_sd:
+                sd[k] = t
+            yield k, t
+    lmm.mesh_decoder.load_state_iter(items(), strict=True)
+    if rank == 0:
+        print(f"[bench] weights generated + loaded in {time.time() - t0:.1f}s", file=sys.stderr)
+
+    def one_step(step_idx):
+        pc = W.synthetic_point_cloud(step_idx * world + rank, args.points).to(dev)      # resident in HBM
+        _, toks = lmm.generate(pc, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+        streams = D.gather_token_streams([toks[0]], world, device=dev)
+        assert len(streams) == world and all(len(s) == T for s in streams)
+        return lmm.mesh_decoder.last_decode_ms
+
+    for w in range(args.warmup):
+        one_step(-1 - w)
+    D.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    dec_ms = [one_step(k) for k in range(args.steps)]
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t_start, dev)
+
+    total_tokens = world * args.steps * T
+    value = total_tokens / elapsed
+    decode_only = world * T / (D.max_over_ranks(float(np.mean(dec_ms)), dev) / 1e3)
+
+    # ---- roofline of the dominant decode kernel, measured live with HIP events on the launch stream
+    prof = lmm.mesh_decoder.profile_decode_kernels(repeats=4)      # at the final context length (2050 + T)
+    per_token_us = {k: v["avg_us"] * LAUNCHES_PER_TOKEN[k] for k, v in prof.items()}
+    dom = max(per_token_us, key=per_token_us.get)
+    ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
+    mean_L = 2050 + (T - 1) / 2.0
+    bytes_per_token = W_ELEMS * 4 + KV_ELEMS_PER_POS * (mean_L + 1) * 4
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+        "bytes_per_launch": prof[dom]["bytes"], "avg_us_per_launch": round(prof[dom]["avg_us"], 3),
+        "context_len_at_measurement": 2050 + T,
+        "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1),
+                        "us_per_token": round(per_token_us[k], 2)} for k, v in prof.items()},
+        "whole_step": {"bytes_per_token": bytes_per_token,
+                       "achieved_GBps": round(decode_only / world * bytes_per_token / 1e9, 1),
+                       "frac": round(decode_only / world * bytes_per_token / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+    out = {
+        "metric": "mesh tokens/sec (whole node), ArAE greedy test_num_face=1000",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: ArAE random-init (seeded synthetic checkpoint), batch 1 per GPU, greedy, "
+                               f"test_num_face={args.num_face}, {T} new tokens (EOS suppressed until T), "
+                               f"{args.points}-point synthetic cloud; step = encode_cond + 2050-token prefill + {T}-token decode"
+                               f"{' + RCCL all-gather of token streams' if world > 1 else ''}",
+                   "layers": args.layers, "hidden": 1536, "heads": 16, "tokens_per_sample": T,
+                   "parallelism": f"dp{world} (independent samples, full replica per GPU)"},
+        "decode_only_tokens_per_s": round(decode_only, 2),
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        out["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_steps, args.points)
+        out["gpu_over_cpu"] = round(out["decode_only_tokens_per_s"] / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

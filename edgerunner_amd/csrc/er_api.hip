@@ -19,6 +19,7 @@
 #include "k_gemv.h"
 #include "k_head.h"
 #include "k_rowops.h"
+#include "meto_decode.h"
 
 using namespace er;
 
@@ -1049,5 +1050,15 @@ extern "C" int er_k_sample_head(const float* logits, const er_decode_params* p, 
     hipFree(sb); hipFree(dpd); hipFree(ids);
     HIPRET(e);
     HIPRET(e2);
+    return ER_OK;
+}
+
+// ------------------------------------------------------------------------------------ detokenise (host)
+extern "C" int er_meto_decode(const int32_t* tokens, int n, int bins, float* v, int32_t* f, int32_t* t, int32_t* nv,
+                              int32_t* nf, int32_t* nt) {
+    if (n < 0 || bins <= 0 || (n > 0 && !tokens) || !v || !f || !t || !nv || !nf || !nt)
+        return fail(ER_ERR_INVALID, "er_meto_decode: bad argument");
+    const MetoCounts c = meto_decode_lr_absco(tokens, n, bins, v, f, t);
+    *nv = c.vertices; *nf = c.faces; *nt = c.face_types;
     return ER_OK;
 }

@@ -117,10 +117,11 @@ class LMM:
     @torch.no_grad()
     def generate(self, conds, num_faces=1000, resume_ids=None, tokenizer=None, max_new_tokens=None, clean=True,
                  min_new_tokens: int = 0, seed: Optional[int] = None):
-        """-> (meshes, all_tokens) like core/models.py:204-319.  Detokenisation
-        (save_mesh -> meto decode -> trimesh, core/provider.py:39-66) is the "next" row
-        of the scope table; until it lands ``meshes`` holds ``None`` placeholders."""
+        """-> (meshes, all_tokens) like core/models.py:204-319.  ``tokenizer`` is a
+        ``edgerunner_amd.meto.Engine`` (or None for the 9-coordinate layout); each mesh is a
+        ``(vertices, faces)`` pair (the reference returns trimesh objects, absent here)."""
         output_ids = self.generate_ids(conds, num_faces, resume_ids, tokenizer, max_new_tokens, min_new_tokens, seed)
+        from .meto import Engine, save_mesh
         meshes: List[Optional[object]] = []
         all_tokens: List[np.ndarray] = []
         out = output_ids.detach().cpu().numpy()
@@ -128,6 +129,10 @@ class LMM:
             tokens = out[b]
             if resume_ids is not None:
                 tokens = np.concatenate((resume_ids[b].detach().cpu().numpy(), tokens), axis=0)
-            meshes.append(None)
+            # batch detokenize (core/models.py:315): (vertices, faces) instead of a trimesh object
+            if tokenizer is None or isinstance(tokenizer, Engine):
+                meshes.append(save_mesh(tokens, self.opt, tokenizer=tokenizer, clean=clean))
+            else:
+                meshes.append(None)      # opaque tokenizer marker (tests / benches): ids only
             all_tokens.append(tokens)
         return meshes, all_tokens

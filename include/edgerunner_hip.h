@@ -137,6 +137,15 @@ int er_feed(er_ctx* ctx, const int32_t* ids_host, void* stream);
 int er_decode(er_ctx* ctx, const er_decode_params* p, int64_t* out_ids_dev,
               int32_t* n_steps_host, void* stream);
 
+/* ---- detokenise (the step right after the decode loop; host code, no device work) ----
+ * Engine_LR_ABSCO::decode (meto/include/meto/engine_lr_absco.h:223-295) + Vertex::undiscrete
+ * (meto/include/meto/mesh.h:36-42), reached from save_mesh/detokenize_mesh
+ * (core/provider.py:39-66,112-147).  tokens_host = meto ids (model ids - 3, cut at EOS).
+ * Capacities: vertices_out float[3*(n/3+3)], faces_out int32[3*(n/4+2)], face_type_out int32[n/4+3]. */
+int er_meto_decode(const int32_t* tokens_host, int n_tokens, int discrete_bins, float* vertices_out,
+                   int32_t* faces_out, int32_t* face_type_out, int32_t* n_vertices, int32_t* n_faces,
+                   int32_t* n_face_types);
+
 /* ---- measurement ---- */
 #define ER_NUM_KERNEL_KINDS 8
 /* kinds: 0 qkv_gemv 1 attn_decode 2 attn_combine 3 out_proj_gemv 4 fc1_gemv 5 fc2_gemv 6 lm_head_gemv 7 sample_head */

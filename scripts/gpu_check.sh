@@ -1,0 +1,25 @@
+#!/bin/bash
+# One gpurun call: kernel unit tests, end-to-end parity, a short bench and a rocprofv3 kernel trace.
+# Usage (build container):  gpurun --timeout 1500 -- 'bash scripts/gpu_check.sh [quick|full]'
+set -u
+MODE=${1:-full}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/device.txt
+python - <<'PY' > gpurun_out/env.txt 2>&1
+import torch, os
+print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0) if torch.cuda.is_available() else None)
+print("cpus", os.cpu_count())
+PY
+echo "== kernel unit tests"; timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider --timeout 300 2>&1 | tail -40 | tee gpurun_out/test_kernels.log
+echo "== parity tests"; timeout 1500 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -p no:cacheprovider --timeout 900 2>&1 | tail -60 | tee gpurun_out/test_parity.log
+if [ "$MODE" = "full" ]; then
+  echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
+  echo "== bench"; timeout 900 python bench.py --steps 2 --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json
+  tail -5 gpurun_out/bench.err
+  echo "== rocprof"; cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/rocprof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/rocprof.err
+  cd $GRAFT_REPO_ROOT; ls -la gpurun_out/prof 2>/dev/null | head; find gpurun_out/prof -name "*stats*" | head
+  # keep only the small summaries (traces are large)
+  find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete 2>/dev/null
+fi
+echo "== done"
