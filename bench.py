@@ -34,28 +34,42 @@ LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "ou
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
 
 
-def cpu_baseline(opt, sd, T_sample, num_points):
+class _Budget(Exception):
+    pass
+
+
+def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
     """Reference CPU-eager path timed on this box's host cores: the oracle (a torch-CPU fp32
     restatement that is bit-identical to the reference's own modules, see oracle/) on a bounded
-    sample of the same workload: encode + prefill + the first T_sample decode steps."""
+    sample of the same workload: encode + prefill + the first decode steps (at most T_sample
+    steps or budget_s seconds of decoding, whichever comes first)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import arae_oracle as O
     from edgerunner_amd import weights as W
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = torch.get_num_threads()          # torch's default = the cores this process may use
     pc = W.synthetic_point_cloud(0, num_points)
     marks = []
+
+    def timer(t):
+        marks.append(time.perf_counter())
+        if len(marks) >= 3 and marks[-1] - marks[0] > budget_s:
+            raise _Budget()
+
     t0 = time.perf_counter()
-    O.lmm_generate_ids(sd, opt, pc, 1000, max_new_tokens=T_sample, min_new_tokens=T_sample,
-                       step_timer=lambda t: marks.append(time.perf_counter()))
-    t1 = time.perf_counter()
+    print(f"[bench] cpu baseline: oracle on {threads} threads ...", file=sys.stderr, flush=True)
+    try:
+        O.lmm_generate_ids(sd, opt, pc, 1000, max_new_tokens=T_sample, min_new_tokens=T_sample, step_timer=timer)
+    except _Budget:
+        pass
     dec = np.diff(np.array(marks))
+    n = len(dec)
     return {
-        "value": round(float(len(dec) / dec.sum()), 3), "unit": "tokens/s", "cores": torch.get_num_threads(),
+        "value": round(float(n / dec.sum()), 3), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"oracle (torch CPU fp32, = reference modules bit-for-bit): encode_cond + 2050-token prefill "
-                  f"({marks[0] - t0:.1f}s) + first {T_sample} greedy decode steps at context 2050..{2050 + T_sample} "
-                  f"({dec.sum():.1f}s); the full run would be slower per token as context grows to 6050",
-        "end_to_end_tokens_per_s_on_sample": round(T_sample / (t1 - t0), 3),
+                  f"({marks[0] - t0:.1f}s) + first {n} greedy decode steps at context 2050..{2050 + n} "
+                  f"({dec.sum():.1f}s); the full 4000-token run is slower per token as context grows to 6050",
+        "prefill_plus_encode_s": round(marks[0] - t0, 2),
     }
 
 
@@ -106,8 +120,13 @@ def main():
         assert len(streams) == world and all(len(s) == T for s in streams)
         return lmm.mesh_decoder.last_decode_ms
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.time() - t0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
     for w in range(args.warmup):
         one_step(-1 - w)
+    log("warmup done")
     D.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -115,6 +134,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t_start, dev)
+    log(f"timed region done: {elapsed:.2f}s")
 
     total_tokens = world * args.steps * T
     value = total_tokens / elapsed
@@ -122,6 +142,7 @@ def main():
 
     # ---- roofline of the dominant decode kernel, measured live with HIP events on the launch stream
     prof = lmm.mesh_decoder.profile_decode_kernels(repeats=4)      # at the final context length (2050 + T)
+    log("kernel sweep done")
     per_token_us = {k: v["avg_us"] * LAUNCHES_PER_TOKEN[k] for k, v in prof.items()}
     dom = max(per_token_us, key=per_token_us.get)
     ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9

@@ -95,6 +95,7 @@ struct er_ctx {
     // hipGraph of one step
     hipGraphExec_t step_exec = nullptr;
     bool use_graph = true;
+    int rw_qkv = 2, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
@@ -185,6 +186,13 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->layers.resize(cfg->num_layers);
     const char* ng = getenv("ER_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
+    auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
+    c->rw_qkv = env_int("ER_RW_QKV", 2);
+    c->rw_fc1 = env_int("ER_RW_FC1", 2);
+    c->rw_fc2 = env_int("ER_RW_FC2", 2);
+    c->rw_out = env_int("ER_RW_OUT", 1);
+    c->attn_steps = env_int("ER_ATTN_STEPS", ATTN_STEPS_DEFAULT);
+    if (c->attn_steps != 2 && c->attn_steps != 8) c->attn_steps = 4;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -392,9 +400,8 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     const size_t kv_elems = (size_t)c->kv_lstride * g.num_layers;
     HIPCHK(hipMalloc(&c->kc, kv_elems * 4));
     HIPCHK(hipMalloc(&c->vc, kv_elems * 4));
-    // split count of the decode attention: ~3 workgroups per CU at batch 1, fewer splits for large batches
-    int S = 48;
-    while (S > 4 && (long long)S * H * batch > 4096) S /= 2;
+    // decode attention: one workgroup per (row, head, chunk of 32*steps keys)
+    const int S = attn_num_chunks(Lcap, c->attn_steps);
     c->S_splits = S;
     const size_t b = (size_t)batch;
     HIPCHK(hipMalloc(&c->ypre, b * hid * 4));
@@ -455,6 +462,15 @@ static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
     return hipSuccess;
 }
 
+template <int KS, int PRO, int EPI>
+static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st) {
+    switch (rw) {
+        case 1: return gemv_groups<KS, 1, PRO, EPI>(a, B, K, st);
+        case 4: return gemv_groups<KS, 4, PRO, EPI>(a, B, K, st);
+        default: return gemv_groups<KS, 2, PRO, EPI>(a, B, K, st);
+    }
+}
+
 static AttnDecArgs attn_args(er_ctx* c, int layer) {
     AttnDecArgs a{};
     a.q = c->qbuf;
@@ -474,17 +490,11 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     return a;
 }
 
-static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int B, hipStream_t st) {
-    const int chunk_max = attn_chunk_max(a.l_cap, a.S);
-    const size_t lds = (size_t)(chunk_max + ER_NWAVES * D + 8) * sizeof(float);
-    if (D == 96) hipLaunchKernelGGL((attn_decode_f32_kernel<96>), dim3(a.S, a.H, B), dim3(ER_WG), lds, st, a, chunk_max);
-    else hipLaunchKernelGGL((attn_decode_f32_kernel<64>), dim3(a.S, a.H, B), dim3(ER_WG), lds, st, a, chunk_max);
-    return hipGetLastError();
+static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int steps, int B, hipStream_t st) {
+    return D == 96 ? launch_attn_partial_d<96>(a, steps, B, st) : launch_attn_partial_d<64>(a, steps, B, st);
 }
-static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int B, hipStream_t st) {
-    if (D == 96) hipLaunchKernelGGL((attn_combine_f32_kernel<96>), dim3(a.H, B), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((attn_combine_f32_kernel<64>), dim3(a.H, B), dim3(128), 0, st, a);
-    return hipGetLastError();
+static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int steps, int B, hipStream_t st) {
+    return D == 96 ? launch_attn_combine_d<96>(a, steps, B, st) : launch_attn_combine_d<64>(a, steps, B, st);
 }
 
 static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, long long* out_ids, int out_ld) {
@@ -504,28 +514,28 @@ static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, lo
             a.vcache = c->vc + (long long)layer * c->kv_lstride;
             if (layer == 0) {
                 a.embd = c->embd; a.posemb = c->posemb; a.tok = c->st.tok;
-                return gemv_groups<1, 2, PRO_EMBED, EPI_QKV>(a, B, H, st);
+                return gemv_rw<1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
             }
             a.xin = c->ypre; a.ln_w = c->layers[layer - 1].ln2w; a.ln_b = c->layers[layer - 1].ln2b;
-            return gemv_groups<1, 2, PRO_LN, EPI_QKV>(a, B, H, st);
+            return gemv_rw<1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st);
         }
-        case 1: return launch_attn_partial(attn_args(c, layer), c->D, B, st);
-        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st);
+        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, B, st);
+        case 2: return launch_attn_combine(attn_args(c, layer), c->D, c->attn_steps, B, st);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             a.W = L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
-            return gemv_groups<1, 1, PRO_NONE, EPI_RESID>(a, B, H, st);
+            return gemv_rw<1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st);
         }
         case 4: {   // h1 = LN1(ypre1); f = relu(fc1 h1 + b)
             const LayerW& L = c->layers[layer];
             a.W = L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
             a.hout = c->h1buf; a.out = c->fbuf;
-            return gemv_groups<1, 2, PRO_LN, EPI_RELU>(a, B, H, st);
+            return gemv_rw<1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
         }
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];
             a.W = L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
-            return gemv_groups<4, 2, PRO_NONE, EPI_RESID>(a, B, I, st);
+            return gemv_rw<4, PRO_NONE, EPI_RESID>(c->rw_fc2, a, B, I, st);
         }
         case 6: {   // logits = lm_head LN2_last(ypre)
             a.W = c->lm_head; a.bias = nullptr; a.N = g.vocab_size; a.xin = c->ypre;
@@ -970,20 +980,22 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
 }
 
 extern "C" int er_k_attn_decode(const float* q, const float* k, const float* v, const int32_t* len_host, float* out, int B,
-                                int heads, int head_dim, int l_cap, int splits, void* stream) {
+                                int heads, int head_dim, int l_cap, int steps, void* stream) {
     if (head_dim != 96 && head_dim != 64) return fail(ER_ERR_UNSUPPORTED, "head_dim %d", head_dim);
+    if (steps != 2 && steps != 4 && steps != 8) return fail(ER_ERR_INVALID, "steps must be 2, 4 or 8 (chunk = 32*steps keys)");
     hipStream_t st = (hipStream_t)stream;
+    const int S = attn_num_chunks(l_cap, steps);
     int* len_dev = nullptr;
     float* part = nullptr;
     HIPCHK(hipMalloc(&len_dev, B * sizeof(int)));
-    HIPCHK(hipMalloc(&part, (size_t)B * heads * splits * (head_dim + 2) * 4));
+    HIPCHK(hipMalloc(&part, (size_t)B * heads * S * (head_dim + 2) * 4));
     HIPCHK(hipMemcpy(len_dev, len_host, B * sizeof(int), hipMemcpyHostToDevice));
     AttnDecArgs a{};
     a.q = q; a.kcache = k; a.vcache = v; a.len_dev = len_dev; a.part = part; a.out = out;
-    a.H = heads; a.l_cap = l_cap; a.S = splits; a.hidden = heads * head_dim;
+    a.H = heads; a.l_cap = l_cap; a.S = S; a.hidden = heads * head_dim;
     a.kv_bstride = (long long)heads * l_cap * head_dim; a.sqrt_d = sqrtf((float)head_dim);
-    hipError_t e = launch_attn_partial(a, head_dim, B, st);
-    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st);
+    hipError_t e = launch_attn_partial(a, head_dim, steps, B, st);
+    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, steps, B, st);
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(len_dev);
     hipFree(part);

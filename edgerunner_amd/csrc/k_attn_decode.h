@@ -8,11 +8,13 @@
 // and the step's K/V row has already been appended by the QKV GEMV epilogue.
 //
 // HBM-bound: reads 2*L*D floats per (batch, head).  With only B*16 (b,h) pairs the
-// key range is split over S workgroups per pair (flash-decoding): each workgroup
-// computes scores for its chunk (8 lanes x 3 float4 cover one 96-float key row: a
-// wave-instruction reads 8 complete 128-byte lines), a chunk-local softmax
-// (max, exp, sum) and the weighted V sum, and writes {m, l, o[D]}; a second tiny
-// kernel merges the S partials exactly as a single softmax would.
+// key range is cut into fixed chunks of 32*STEPS keys, one workgroup per chunk
+// (flash-decoding).  8 lanes x NV float4 cover one key row, so a wave-instruction
+// reads 8 complete 128-byte lines.  Every wave issues ALL of its K and V loads
+// (2*STEPS*NV float4 per lane) before touching any of them: one HBM round trip per
+// workgroup instead of one per loop iteration.  Scores, the chunk-local softmax and
+// the weighted V sum then run out of registers; the workgroup writes {m, l, o[D]} and
+// a second tiny kernel merges the partials of a head exactly as one softmax would.
 #pragma once
 #include "er_common.h"
 
@@ -23,11 +25,11 @@ struct AttnDecArgs {
     const float* kcache;   // [B][H][Lcap][D]
     const float* vcache;
     const int* pos;        // device, per row: index of the newest key (len = pos+1); or
-    int fixed_len;         // >0: use this length for every row instead of pos (unit tests)
+    int fixed_len;         // >0: use this length for every row instead of pos
     const int* len_dev;    // optional per-row lengths (overrides pos when non-null)
     float* part;           // [B][H][S][D+2] = {m, l, o[0..D)}
     float* out;            // combine: [B][hidden]
-    int H, l_cap, S, hidden;
+    int H, l_cap, S, hidden;   // S = number of chunks the grid covers = ceil(l_cap / chunk)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
 };
@@ -38,78 +40,87 @@ __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
     return a.pos[b] + 1;
 }
 
-// grid (S, H, B), 256 threads.  Dynamic LDS: chunk_max floats (scores) + 4*D + 8.
-template <int D>
-__global__ __launch_bounds__(ER_WG) void attn_decode_f32_kernel(AttnDecArgs a, int chunk_max) {
+// grid (S, H, B), 256 threads; chunk = 32*STEPS keys: wave w, step i, lane group g -> key k0 + 32*i + 8*w + g.
+template <int D, int STEPS>
+__global__ __launch_bounds__(ER_WG) void attn_decode_f32_kernel(AttnDecArgs a) {
     constexpr int NV = D / 32;   // float4 per lane per key (8 lanes per key)
+    constexpr int CHUNK = 32 * STEPS;
     static_assert(D % 32 == 0, "head_dim must be a multiple of 32");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sc = smem;                         // [chunk_max]
-    float* ored = smem + chunk_max;           // [4][D]
-    float* red = ored + ER_NWAVES * D;        // [8]
+    __shared__ __attribute__((aligned(16))) float ored[ER_NWAVES * D];
+    __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & 7, g = lane >> 3;
     const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int len = attn_len(a, b);
-    int chunk = (len + a.S - 1) / a.S;
-    chunk = (chunk + 31) & ~31;
-    const int k0 = s * chunk;
-    const int k1 = min(len, k0 + chunk);
-    float* pout = a.part + (((long long)b * a.H + h) * a.S + s) * (D + 2);
-    if (k0 >= len) {                          // empty split: neutral element of the merge
-        if (tid < D + 2) pout[tid] = (tid == 0) ? -INFINITY : 0.0f;
-        return;
+    const int k0 = s * CHUNK;
+    if (k0 >= len) return;                    // inactive chunk: the merge only visits ceil(len/CHUNK) partials
+    const int k1 = min(len, k0 + CHUNK);
+    const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
+    const float* kb = a.kcache + head_off;
+    const float* vb = a.vcache + head_off;
+
+    // ---- all loads first: K rows, then V rows (K returns first, V lands while the scores are reduced)
+    f32x4 kreg[STEPS][NV], vreg[STEPS][NV];
+    bool valid[STEPS];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int kk = k0 + 32 * i + 8 * wid + g;
+        valid[i] = kk < k1;
+        const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) kreg[i][j] = kr[j * 8 + p];
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int kk = k0 + 32 * i + 8 * wid + g;
+        const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) vreg[i][j] = vr[j * 8 + p];
     }
     f32x4 qv[NV];
     const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (long long)b * a.hidden + h * D);
 #pragma unroll
     for (int j = 0; j < NV; ++j) qv[j] = qp[j * 8 + p];
-    const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
 
-    // ---- pass 1: scores of this chunk
-    const float* kb = a.kcache + head_off;
+    // ---- scores q.k / sqrt(D) (every lane of an 8-lane group ends up holding its key's score)
+    float sc[STEPS];
     float mloc = -INFINITY;
-#pragma unroll 2
-    for (int kk = k0 + wid * 8 + g; kk < k1; kk += 32) {
-        const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)kk * D);
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) acc = dot4(qv[j], kr[j * 8 + p], acc);
+        for (int j = 0; j < NV; ++j) acc = dot4(qv[j], kreg[i][j], acc);
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
-        const float sv = acc / a.sqrt_d;
-        if (p == 0) sc[kk - k0] = sv;
-        mloc = fmaxf(mloc, sv);
+        sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
+        mloc = fmaxf(mloc, sc[i]);
     }
-    const float m = block_max(mloc, red);     // barriers inside also publish sc[]
-    const int n = k1 - k0;
+    const float m = block_max(mloc, red);     // finite: the chunk holds at least one key
+
+    // ---- chunk-local softmax weights and their sum (each key counted once: lanes with p == 0)
+    float pw[STEPS];
     float lloc = 0.f;
-    for (int i = tid; i < n; i += ER_WG) {
-        const float e = expf(sc[i] - m);
-        sc[i] = e;
-        lloc += e;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        pw[i] = valid[i] ? expf(sc[i] - m) : 0.f;
+        if (p == 0) lloc += pw[i];
     }
     const float l = block_sum(lloc, red);
 
-    // ---- pass 2: o = sum_k p_k V_k
-    const float* vb = a.vcache + head_off;
+    // ---- o = sum_k p_k V_k
     f32x4 o[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int kk = k0 + wid * 8 + g; kk < k1; kk += 32) {
-        const float pw = sc[kk - k0];
-        const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)kk * D);
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i)
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const f32x4 v = vr[j * 8 + p];
-            o[j].x = fmaf(pw, v.x, o[j].x);
-            o[j].y = fmaf(pw, v.y, o[j].y);
-            o[j].z = fmaf(pw, v.z, o[j].z);
-            o[j].w = fmaf(pw, v.w, o[j].w);
+            o[j].x = fmaf(pw[i], vreg[i][j].x, o[j].x);
+            o[j].y = fmaf(pw[i], vreg[i][j].y, o[j].y);
+            o[j].z = fmaf(pw[i], vreg[i][j].z, o[j].z);
+            o[j].w = fmaf(pw[i], vreg[i][j].w, o[j].w);
         }
-    }
     // sum over the 8 key groups of the wave (lanes with equal p), then over the 4 waves
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -126,38 +137,46 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_f32_kernel(AttnDecArgs a, i
         for (int j = 0; j < NV; ++j) reinterpret_cast<f32x4*>(ored + wid * D)[j * 8 + p] = o[j];
     }
     __syncthreads();
+    float* pout = a.part + (((long long)b * a.H + h) * a.S + s) * (D + 2);
     if (tid < D) pout[2 + tid] = (ored[tid] + ored[D + tid]) + (ored[2 * D + tid] + ored[3 * D + tid]);
     if (tid == 0) { pout[0] = m; pout[1] = l; }
 }
 
-// grid (H, B), 128 threads (>= D): merge the S partial softmaxes of one (b, h).
-template <int D>
+// grid (H, B), 128 threads (>= D): merge the active partial softmaxes of one (b, h).
+template <int D, int STEPS>
 __global__ __launch_bounds__(128) void attn_combine_f32_kernel(AttnDecArgs a) {
+    constexpr int CHUNK = 32 * STEPS;
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int n_act = (attn_len(a, b) + CHUNK - 1) / CHUNK;
     const float* pb = a.part + ((long long)b * a.H + h) * a.S * (D + 2);
     float M = -INFINITY;
-    for (int s = 0; s < a.S; ++s) M = fmaxf(M, pb[s * (D + 2)]);
+    for (int s = 0; s < n_act; ++s) M = fmaxf(M, pb[s * (D + 2)]);
     float l = 0.f, o = 0.f;
-    for (int s = 0; s < a.S; ++s) {
-        const float ms = pb[s * (D + 2)];
-        if (ms == -INFINITY) continue;        // empty split
-        const float w = expf(ms - M);
+    for (int s = 0; s < n_act; ++s) {
+        const float w = expf(pb[s * (D + 2)] - M);
         l = fmaf(pb[s * (D + 2) + 1], w, l);
         if (tid < D) o = fmaf(pb[s * (D + 2) + 2 + tid], w, o);
     }
     if (tid < D) a.out[(long long)b * a.hidden + h * D + tid] = o / l;
 }
 
-inline int attn_chunk_max(int l_cap, int S) { return (((l_cap + S - 1) / S) + 31) & ~31; }
+constexpr int ATTN_STEPS_DEFAULT = 4;          // 128 keys per workgroup
+inline int attn_num_chunks(int l_cap, int steps) { return (l_cap + 32 * steps - 1) / (32 * steps); }
 
 template <int D>
-inline hipError_t launch_attn_decode(const AttnDecArgs& a, int B, hipStream_t st) {
-    const int chunk_max = attn_chunk_max(a.l_cap, a.S);
-    const size_t lds = (size_t)(chunk_max + ER_NWAVES * D + 8) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_f32_kernel<D>), dim3(a.S, a.H, B), dim3(ER_WG), lds, st, a, chunk_max);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((attn_combine_f32_kernel<D>), dim3(a.H, B), dim3(128), 0, st, a);
+inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, int B, hipStream_t st) {
+    const dim3 grid(a.S, a.H, B), blk(ER_WG);
+    if (steps == 2) hipLaunchKernelGGL((attn_decode_f32_kernel<D, 2>), grid, blk, 0, st, a);
+    else if (steps == 8) hipLaunchKernelGGL((attn_decode_f32_kernel<D, 8>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((attn_decode_f32_kernel<D, 4>), grid, blk, 0, st, a);
+    return hipGetLastError();
+}
+template <int D>
+inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int steps, int B, hipStream_t st) {
+    const dim3 grid(a.H, B), blk(128);
+    if (steps == 2) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 2>), grid, blk, 0, st, a);
+    else if (steps == 8) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 8>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((attn_combine_f32_kernel<D, 4>), grid, blk, 0, st, a);
     return hipGetLastError();
 }
 

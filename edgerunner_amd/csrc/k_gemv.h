@@ -79,6 +79,19 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
     float* xs = smem;              // [NB][K]
     float* red = smem + NB * K;    // 64 floats
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int slice = (KS == 1) ? 0 : wid;                 // K-slice this wave reduces
+    const int row0 = (KS == 1) ? (blockIdx.x * ER_NWAVES + wid) * RW : blockIdx.x * RW;
+
+    // ---------------- issue this wave's weight loads first: they do not depend on the prologue, so the
+    // HBM round trip (~1-2 us) overlaps the LayerNorm reductions instead of following them
+    f32x4 w[RW][J];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = min(row0 + r, a.N - 1);            // clamp: out-of-range rows are loaded but never stored
+        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W + (long long)row * K + slice * (J * 256));
+#pragma unroll
+        for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
+    }
 
     // ---------------- prologue: build the input vector(s) in LDS
 #pragma unroll
@@ -119,9 +132,7 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
     }
     __syncthreads();
 
-    // ---------------- main: stream the weight rows
-    const int slice = (KS == 1) ? 0 : wid;                 // K-slice this wave reduces
-    const int row0 = (KS == 1) ? (blockIdx.x * ER_NWAVES + wid) * RW : blockIdx.x * RW;
+    // ---------------- main: dot the (already in flight) weight rows with the input
     f32x4 xr[NB][J];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -129,14 +140,6 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
         for (int j = 0; j < J; ++j)
             xr[b][j] = reinterpret_cast<const f32x4*>(xs + b * K + slice * (J * 256))[j * 64 + lane];
 
-    f32x4 w[RW][J];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int row = min(row0 + r, a.N - 1);            // clamp: out-of-range rows are loaded but never stored
-        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W + (long long)row * K + slice * (J * 256));
-#pragma unroll
-        for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
-    }
     float acc[RW][NB];
 #pragma unroll
     for (int r = 0; r < RW; ++r)

@@ -16,10 +16,15 @@ echo "== parity tests"; timeout 1500 python -m pytest tests/test_gpu_parity.py -
 if [ "$MODE" = "full" ]; then
   echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
   echo "== bench"; timeout 900 python bench.py --steps 2 --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json
-  tail -5 gpurun_out/bench.err
-  echo "== rocprof"; cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/rocprof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/rocprof.err
-  cd $GRAFT_REPO_ROOT; ls -la gpurun_out/prof 2>/dev/null | head; find gpurun_out/prof -name "*stats*" | head
-  # keep only the small summaries (traces are large)
-  find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete 2>/dev/null
+  tail -30 gpurun_out/bench.err
+  echo "== rocprof"; rm -rf /tmp/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/rocprof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/rocprof.err)
+  mkdir -p gpurun_out/prof; find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \; ; ls -la /tmp/prof gpurun_out/prof | head -20
+  head -12 gpurun_out/prof/*kernel_stats.csv 2>/dev/null; tail -3 gpurun_out/rocprof.err; cat gpurun_out/rocprof_bench.json
 fi
+if [ "$MODE" = "tune" ] || [ "$MODE" = "full" ]; then
+  echo "== tune"
+  TUNE_CONFIGS='[{"ER_ATTN_STEPS":2},{"ER_ATTN_STEPS":8},{"ER_RW_FC1":1},{"ER_RW_FC1":4},{"ER_RW_QKV":1},{"ER_RW_QKV":4},{"ER_RW_FC2":1},{"ER_RW_FC2":4},{"ER_RW_OUT":2},{"ER_NO_GRAPH":1}]' \
+    timeout 900 python scripts/tune_decode.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/tune.log
+fi
+du -sh gpurun_out
 echo "== done"

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""In-process sweep of the decode tuning knobs (env vars read by er_create).  GPU box only.
+Prints decode tok/s (T tokens after a 2050-token prefill) and the per-kernel-kind sweep per config."""
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from edgerunner_amd import weights as W  # noqa: E402
+from edgerunner_amd.models import LMM  # noqa: E402
+from edgerunner_amd.options import config_defaults  # noqa: E402
+
+T = int(os.environ.get("TUNE_TOKENS", "1000"))
+CONFIGS = [dict()] + [dict(c) for c in json.loads(os.environ.get("TUNE_CONFIGS", "[]"))]
+KNOBS = ["ER_RW_QKV", "ER_RW_FC1", "ER_RW_FC2", "ER_RW_OUT", "ER_ATTN_STEPS", "ER_NO_GRAPH"]
+
+
+def main():
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=24, generate_mode="greedy")
+    t0 = time.time()
+    sd = W.make_state_dict(opt, 0, "perturbed")
+    print(f"weights in {time.time() - t0:.1f}s", flush=True)
+    pc = W.synthetic_point_cloud(0, 4096).to("cuda:0")
+    ref = None
+    for cfg in CONFIGS:
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        for k, v in cfg.items():
+            os.environ[k] = str(v)
+        lmm = LMM(opt, "cuda:0")
+        lmm.load_state_dict(sd, strict=True)
+        best = 0.0
+        for rep in range(2):
+            _, toks = lmm.generate(pc, 1000, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+            best = max(best, T / lmm.mesh_decoder.last_decode_ms * 1e3)
+        if ref is None:
+            ref = toks[0].copy()
+        same = bool((toks[0] == ref).all())
+        prof = lmm.mesh_decoder.profile_decode_kernels(repeats=3)
+        per_tok = sum(v["avg_us"] * (24 if k not in ("lm_head_gemv", "sample_head") else 1) for k, v in prof.items())
+        print(json.dumps({"cfg": cfg, "decode_tok_s": round(best, 1), "ids_equal_base": same,
+                          "sweep_us_per_token": round(per_tok, 1),
+                          "kinds_us": {k: round(v["avg_us"], 2) for k, v in prof.items()},
+                          "kinds_GBps": {k: round(v["bytes"] / v["avg_us"] / 1e3, 0) for k, v in prof.items()}}), flush=True)
+        lmm.mesh_decoder.close()
+        del lmm
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,9 +69,9 @@ def test_gemv_fc2_ksplit_resid(B):
 
 
 # ------------------------------------------------------------------ decode attention
-@pytest.mark.parametrize("D,lens,splits", [(96, [2051], 48), (96, [1, 33], 48), (96, [6049, 4000, 17], 48),
-                                           (64, [300], 8), (96, [2050], 1)])
-def test_attn_decode(D, lens, splits):
+@pytest.mark.parametrize("D,lens,steps", [(96, [2051], 4), (96, [1, 33], 4), (96, [6049, 4000, 17], 4),
+                                          (64, [300], 4), (96, [2050, 129], 2), (96, [2050, 255, 256, 257], 8)])
+def test_attn_decode(D, lens, steps):
     from edgerunner_amd import kernels as K
     B, H = len(lens), 16
     Lcap = (max(lens) + 31) // 32 * 32
@@ -81,7 +81,7 @@ def test_attn_decode(D, lens, splits):
     for b, n in enumerate(lens):
         kc[b, :, n:] = float("nan")
         vc[b, :, n:] = float("nan")
-    out = K.attn_decode(q, kc, vc, lens, splits)
+    out = K.attn_decode(q, kc, vc, lens, steps)
     for b, n in enumerate(lens):
         qq = q[b].view(H, 1, D).double()
         w = torch.softmax(qq @ kc[b, :, :n].double().transpose(1, 2) / math.sqrt(D), dim=-1)
@@ -97,10 +97,11 @@ def test_gemm_nt_asymmetric(M, N, K):
     from edgerunner_amd import kernels as K_
     a, w = rnd(M, K, seed=30), rnd(N, K, seed=31)
     bias, resid = rnd(N, seed=32), rnd(M, N, seed=33)
+    tol = 1e-5 + 4e-7 * K          # sequential fp32 accumulation of K unit-variance products
     c = K_.gemm(a, w, bias, resid, relu=False)
-    close(c, a.double() @ w.double().T + bias.double() + resid.double(), 1e-4, 1e-5, "gemm nt")
+    close(c, a.double() @ w.double().T + bias.double() + resid.double(), tol, 1e-5, "gemm nt")
     c2 = K_.gemm(a, w, bias, None, relu=True)
-    close(c2, torch.relu(a.double() @ w.double().T + bias.double()), 1e-4, 1e-5, "gemm nt relu")
+    close(c2, torch.relu(a.double() @ w.double().T + bias.double()), tol, 1e-5, "gemm nt relu")
 
 
 def test_gemm_identity_layout():
@@ -116,7 +117,7 @@ def test_gemm_nn(M, N, K):
     from edgerunner_amd import kernels as K_
     a, b = rnd(M, K, seed=34), rnd(K, N, seed=35)
     c = K_.gemm(a, b, b_is_kn=True)
-    close(c, a.double() @ b.double(), 1e-4, 1e-5, "gemm nn")
+    close(c, a.double() @ b.double(), 1e-5 + 4e-7 * K, 1e-5, "gemm nn")
 
 
 def test_gemm_scale_div():
