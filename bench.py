@@ -46,8 +46,28 @@ def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import arae_oracle as O
     from edgerunner_amd import weights as W
-    threads = torch.get_num_threads()          # torch's default = the cores this process may use
+    default_threads = torch.get_num_threads()  # torch's default = the cores this process may use
     pc = W.synthetic_point_cloud(0, num_points)
+    # pick the thread count the CPU path runs fastest with (a 1-row GEMV stream does not scale to 100+ threads):
+    # time a few cached decode steps of a 2-layer slice of the same model per candidate
+    cand = sorted({t for t in (8, 16, 32, 64, default_threads) if t <= default_threads})
+    probe_opt = dataclasses.replace(opt, num_layers=2)
+    probe_sd = {k: v for k, v in sd.items() if ".layers." not in k or int(k.split(".layers.")[1].split(".")[0]) < 2}
+    emb = torch.randn(1, 2050, opt.hidden_dim) * 0.5
+    timings = {}
+    for t in cand:
+        torch.set_num_threads(t)
+        fwd = O.make_forward(probe_sd, probe_opt)
+        _, past = fwd(inputs_embeds=emb)
+        ids = torch.tensor([[7]])
+        fwd(input_ids=ids, past=past)
+        t1 = time.perf_counter()
+        for _ in range(6):
+            fwd(input_ids=ids, past=past)
+        timings[t] = (time.perf_counter() - t1) / 6
+    threads = min(timings, key=timings.get)
+    torch.set_num_threads(threads)
+    print(f"[bench] cpu baseline: thread probe (s/step, 2 layers) {timings} -> {threads} threads", file=sys.stderr, flush=True)
     marks = []
 
     def timer(t):
@@ -56,7 +76,6 @@ def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
             raise _Budget()
 
     t0 = time.perf_counter()
-    print(f"[bench] cpu baseline: oracle on {threads} threads ...", file=sys.stderr, flush=True)
     try:
         O.lmm_generate_ids(sd, opt, pc, 1000, max_new_tokens=T_sample, min_new_tokens=T_sample, step_timer=timer)
     except _Budget:
@@ -65,6 +84,7 @@ def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
     n = len(dec)
     return {
         "value": round(float(n / dec.sum()), 3), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(),
+        "thread_probe_s_per_step_2layers": {str(k): round(v, 5) for k, v in timings.items()},
         "kind": "port",
         "sample": f"oracle (torch CPU fp32, = reference modules bit-for-bit): encode_cond + 2050-token prefill "
                   f"({marks[0] - t0:.1f}s) + first {n} greedy decode steps at context 2050..{2050 + n} "

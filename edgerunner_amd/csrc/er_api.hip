@@ -95,7 +95,7 @@ struct er_ctx {
     // hipGraph of one step
     hipGraphExec_t step_exec = nullptr;
     bool use_graph = true;
-    int rw_qkv = 2, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
+    int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
@@ -187,7 +187,7 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     const char* ng = getenv("ER_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
-    c->rw_qkv = env_int("ER_RW_QKV", 2);
+    c->rw_qkv = env_int("ER_RW_QKV", 1);
     c->rw_fc1 = env_int("ER_RW_FC1", 2);
     c->rw_fc2 = env_int("ER_RW_FC2", 2);
     c->rw_out = env_int("ER_RW_OUT", 1);
@@ -929,7 +929,10 @@ extern "C" int er_profile_decode_kernels(er_ctx* c, int repeats, float* avg_us, 
             int launches = 0;
             for (int r = 0; r < reps; ++r) {
                 if (per_layer) {
-                    for (int l = 0; l < nl; ++l) { HIPRET(launch_kind(c, kind, l, st, dummy_ids, 8)); ++launches; }
+                    // ER_PROF_LAYERS=n restricts the sweep to the first n layers (cache-residency experiments)
+                    const char* pl = getenv("ER_PROF_LAYERS");
+                    const int span = (pl && atoi(pl) > 0 && atoi(pl) < nl) ? atoi(pl) : nl;
+                    for (int l = 0; l < nl; ++l) { HIPRET(launch_kind(c, kind, l % span, st, dummy_ids, 8)); ++launches; }
                 } else {
                     for (int l = 0; l < nl; ++l) {   // same number of back-to-back launches
                         if (kind == 7) {   // keep the head's step counter in range

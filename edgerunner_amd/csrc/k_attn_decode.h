@@ -142,22 +142,51 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_f32_kernel(AttnDecArgs a) {
     if (tid == 0) { pout[0] = m; pout[1] = l; }
 }
 
-// grid (H, B), 128 threads (>= D): merge the active partial softmaxes of one (b, h).
+// grid (H, B), 256 threads: merge the active partial softmaxes of one (b, h).  Latency-bound (a few KB
+// from L2), so it is organised as two rounds of independent loads instead of a serial walk over the
+// partials: round 1 fetches every {m_s, l_s} at once (one per thread) and turns them into the merge
+// weights w_s = exp(m_s - M) in LDS; round 2 has thread (c, half) accumulate column c over the
+// partials of its half with unrolled, independent loads.
 template <int D, int STEPS>
-__global__ __launch_bounds__(128) void attn_combine_f32_kernel(AttnDecArgs a) {
+__global__ __launch_bounds__(ER_WG) void attn_combine_f32_kernel(AttnDecArgs a) {
     constexpr int CHUNK = 32 * STEPS;
+    constexpr int W = D + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [S] merge weights + [128] half sums + [8]
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int n_act = (attn_len(a, b) + CHUNK - 1) / CHUNK;
-    const float* pb = a.part + ((long long)b * a.H + h) * a.S * (D + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < n_act; ++s) M = fmaxf(M, pb[s * (D + 2)]);
-    float l = 0.f, o = 0.f;
-    for (int s = 0; s < n_act; ++s) {
-        const float w = expf(pb[s * (D + 2)] - M);
-        l = fmaf(pb[s * (D + 2) + 1], w, l);
-        if (tid < D) o = fmaf(pb[s * (D + 2) + 2 + tid], w, o);
+    float* wts = smem;
+    float* half1 = smem + a.S;
+    float* red = half1 + 128;
+    const float* pb = a.part + ((long long)b * a.H + h) * a.S * W;
+    // round 1
+    float mloc = -INFINITY;
+    for (int s = tid; s < n_act; s += ER_WG) mloc = fmaxf(mloc, pb[s * W]);
+    const float M = block_max(mloc, red);
+    float lloc = 0.f;
+    for (int s = tid; s < n_act; s += ER_WG) {
+        const float w = expf(pb[s * W] - M);
+        wts[s] = w;
+        lloc = fmaf(pb[s * W + 1], w, lloc);
     }
-    if (tid < D) a.out[(long long)b * a.hidden + h * D + tid] = o / l;
+    const float l = block_sum(lloc, red);            // barriers inside publish wts[]
+    // round 2
+    const int c = tid & 127, half = tid >> 7;
+    float o = 0.f;
+    if (c < D) {
+        const float* col = pb + 2 + c;
+        int s = half;
+        for (; s + 14 < n_act; s += 16) {            // 8 independent loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(s + 2 * u) * W];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o = fmaf(v[u], wts[s + 2 * u], o);
+        }
+        for (; s < n_act; s += 2) o = fmaf(col[s * W], wts[s], o);
+    }
+    if (half == 1) half1[c] = o;
+    __syncthreads();
+    if (half == 0 && c < D) a.out[(long long)b * a.hidden + h * D + c] = (o + half1[c]) / l;
 }
 
 constexpr int ATTN_STEPS_DEFAULT = 4;          // 128 keys per workgroup
@@ -173,10 +202,11 @@ inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, int B, 
 }
 template <int D>
 inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int steps, int B, hipStream_t st) {
-    const dim3 grid(a.H, B), blk(128);
-    if (steps == 2) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 2>), grid, blk, 0, st, a);
-    else if (steps == 8) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 8>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((attn_combine_f32_kernel<D, 4>), grid, blk, 0, st, a);
+    const dim3 grid(a.H, B), blk(ER_WG);
+    const size_t lds = (size_t)(a.S + 128 + 8) * sizeof(float);
+    if (steps == 2) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 2>), grid, blk, lds, st, a);
+    else if (steps == 8) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 8>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((attn_combine_f32_kernel<D, 4>), grid, blk, lds, st, a);
     return hipGetLastError();
 }
 

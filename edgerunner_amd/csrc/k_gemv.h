@@ -48,15 +48,29 @@ struct GemvArgs {
     long long kv_bstride;  // H*Lcap*D
 };
 
+// bias / residual / cache position are fetched at kernel entry (EpiPre) so that the epilogue after the
+// reduction is pure arithmetic + one store instead of a chain of dependent L2 round trips.
+struct EpiPre { float bias; float resid; int pos; };
+
 template <int EPI>
-__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, float v) {
-    if (a.bias) v += a.bias[n];
+__device__ __forceinline__ EpiPre gemv_epi_prefetch(const GemvArgs& a, int n, int b) {
+    EpiPre e{0.f, 0.f, 0};
+    n = min(n, a.N - 1);
+    if (a.bias) e.bias = a.bias[n];
+    if (EPI == EPI_RESID) e.resid = a.resid[(long long)b * a.N + n];
+    if (EPI == EPI_QKV) e.pos = a.pos[b];
+    return e;
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, float v, const EpiPre& e) {
+    v += e.bias;
     if (EPI == EPI_STORE) {
         a.out[(long long)b * a.N + n] = v;
     } else if (EPI == EPI_RELU) {
         a.out[(long long)b * a.N + n] = fmaxf(v, 0.0f);
     } else if (EPI == EPI_RESID) {
-        a.out[(long long)b * a.N + n] = v + a.resid[(long long)b * a.N + n];
+        a.out[(long long)b * a.N + n] = v + e.resid;
     } else {  // EPI_QKV: rows [0,hidden) = q, [hidden,2h) = k, [2h,3h) = v
         const int which = n / a.hidden;
         const int c = n - which * a.hidden;
@@ -65,7 +79,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, f
         } else {
             const int h = c / a.head_dim, d = c - h * a.head_dim;
             float* cache = (which == 1) ? a.kcache : a.vcache;
-            cache[(long long)b * a.kv_bstride + ((long long)h * a.l_cap + a.pos[b]) * a.head_dim + d] = v;
+            cache[(long long)b * a.kv_bstride + ((long long)h * a.l_cap + e.pos) * a.head_dim + d] = v;
         }
     }
 }
@@ -91,6 +105,18 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
         const f32x4* wr = reinterpret_cast<const f32x4*>(a.W + (long long)row * K + slice * (J * 256));
 #pragma unroll
         for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
+    }
+
+    // epilogue operands of the (row, batch) pairs this thread will finish
+    EpiPre pre[RW][NB];
+    if (KS == 1) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) pre[r][b] = gemv_epi_prefetch<EPI>(a, row0 + r, b);
+    } else {
+        const int t = min(tid, RW * NB - 1);
+        pre[0][0] = gemv_epi_prefetch<EPI>(a, row0 + t / NB, t % NB);
     }
 
     // ---------------- prologue: build the input vector(s) in LDS
@@ -155,9 +181,10 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < RW; ++r)
-                if (row0 + r < a.N)
+                if (row0 + r < a.N) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) gemv_epilogue<EPI>(a, row0 + r, b, acc[r][b]);
+                    for (int b = 0; b < NB; ++b) gemv_epilogue<EPI>(a, row0 + r, b, acc[r][b], pre[r][b]);
+                }
         }
     } else {
         if (lane == 0) {
@@ -172,7 +199,7 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < KS; ++k) s += red[tid * KS + k];
-            if (row0 + r < a.N) gemv_epilogue<EPI>(a, row0 + r, b, s);
+            if (row0 + r < a.N) gemv_epilogue<EPI>(a, row0 + r, b, s, pre[0][0]);
         }
     }
 }

@@ -21,9 +21,18 @@ if [ "$MODE" = "full" ]; then
   mkdir -p gpurun_out/prof; find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \; ; ls -la /tmp/prof gpurun_out/prof | head -20
   head -12 gpurun_out/prof/*kernel_stats.csv 2>/dev/null; tail -3 gpurun_out/rocprof.err; cat gpurun_out/rocprof_bench.json
 fi
+if [ "$MODE" = "full" ]; then
+  echo "== pmc (separate passes, kernel-trace only)"
+  for CNT in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$CNT; (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d /tmp/pmc_$CNT -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --tokens 300 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$CNT.err)
+    ls -la /tmp/pmc_$CNT | head -5
+  done
+  python scripts/pmc_summary.py pmc $(find /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv") > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.err
+  head -c 3000 gpurun_out/pmc_summary.json; tail -3 gpurun_out/pmc_summary.err
+fi
 if [ "$MODE" = "tune" ] || [ "$MODE" = "full" ]; then
   echo "== tune"
-  TUNE_CONFIGS='[{"ER_ATTN_STEPS":2},{"ER_ATTN_STEPS":8},{"ER_RW_FC1":1},{"ER_RW_FC1":4},{"ER_RW_QKV":1},{"ER_RW_QKV":4},{"ER_RW_FC2":1},{"ER_RW_FC2":4},{"ER_RW_OUT":2},{"ER_NO_GRAPH":1}]' \
+  TUNE_CONFIGS=${TUNE_CONFIGS:-'[{"ER_ATTN_STEPS":2},{"ER_ATTN_STEPS":8},{"ER_RW_QKV":2},{"ER_PROF_LAYERS":2},{"ER_PROF_LAYERS":4}]'} \
     timeout 900 python scripts/tune_decode.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/tune.log
 fi
 du -sh gpurun_out

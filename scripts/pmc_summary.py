@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 CSV output into small JSON summaries that can be committed under profiles/.
+
+  pmc_summary.py stats  <kernel_stats.csv>                 -> per-kernel calls / avg us / % (from --kernel-trace --stats)
+  pmc_summary.py pmc    <counter_collection.csv> [...]     -> per-kernel mean counter values per dispatch
+
+HBM traffic per launch (MI355X_MICROARCH.md, section HBM): FETCH_SIZE / WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so
+read_bytes = 2 * FETCH_SIZE * 1024, write_bytes = WRITE_SIZE * 1024 (write side uncalibrated).
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    m = re.search(r"(gemv_f32_kernel<[^>]*>|attn_decode_f32_kernel<[^>]*>|attn_combine_f32_kernel<[^>]*>|[A-Za-z_0-9]+_kernel)", name)
+    return m.group(1) if m else name[:80]
+
+
+def stats(path):
+    rows = list(csv.DictReader(open(path)))
+    out = []
+    for r in rows:
+        out.append({"kernel": short(r.get("Name", "")), "calls": int(r.get("Calls", 0)),
+                    "total_ms": round(float(r.get("TotalDurationNs", 0)) / 1e6, 3),
+                    "avg_us": round(float(r.get("AverageNs", 0)) / 1e3, 3),
+                    "min_us": round(float(r.get("MinNs", 0)) / 1e3, 3), "max_us": round(float(r.get("MaxNs", 0)) / 1e3, 3),
+                    "pct": float(r.get("Percentage", 0))})
+    print(json.dumps({"source": path, "kernels": out}, indent=1))
+
+
+def pmc(paths):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for path in paths:
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            a = acc[k][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    out = {}
+    for k, cs in acc.items():
+        d = {c: {"mean": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()}
+        if "FETCH_SIZE" in d:
+            d["hbm_read_bytes_per_launch"] = 2.0 * d["FETCH_SIZE"]["mean"] * 1024.0     # gfx950 x2 correction
+        if "WRITE_SIZE" in d:
+            d["hbm_write_bytes_per_launch"] = d["WRITE_SIZE"]["mean"] * 1024.0
+        out[k] = d
+    print(json.dumps({"sources": paths, "kernels": out}, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2:])
