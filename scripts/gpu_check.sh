@@ -24,7 +24,7 @@ fi
 if [ "$MODE" = "full" ]; then
   echo "== pmc (separate passes, kernel-trace only)"
   for CNT in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/pmc_$CNT; (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d /tmp/pmc_$CNT -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --tokens 300 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$CNT.err)
+    rm -rf /tmp/pmc_$CNT; (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d /tmp/pmc_$CNT -o pmc -- env ER_NO_GRAPH=1 python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --tokens 300 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$CNT.err)
     ls -la /tmp/pmc_$CNT | head -5
   done
   python scripts/pmc_summary.py pmc $(find /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv") > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.err
