@@ -34,6 +34,26 @@ LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "ou
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
 
 
+KIND_TO_KERNEL = {"qkv_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 3>", "attn_decode": "attn_decode_f32_kernel<96, 4>",
+                  "attn_combine": "attn_combine_f32_kernel<96, 4>", "out_proj_gemv": "gemv_f32_kernel<6, 1, 1, 1, 0, 2>",
+                  "fc1_gemv": "gemv_f32_kernel<6, 1, 1, 2, 1, 1>", "fc2_gemv": "gemv_f32_kernel<6, 4, 1, 2, 0, 2>",
+                  "lm_head_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 0>", "sample_head": "sample_head_kernel"}
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_summary.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes;
+    separate --pmc runs, see scripts/gpu_pmc.sh).  Counters cannot be read inside the timed process."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_summary.json")
+    try:
+        k = json.load(open(path))["kernels"][KIND_TO_KERNEL[kind]]
+        note = " (attention measured at context 2050..2062: 2*L*1536*4 B algorithmic there)" if kind == "attn_decode" else ""
+        return {"bytes": round(k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)),
+                "source": "profiles/r01_pmc_hbm_summary.json" + note}
+    except Exception:
+        return {}
+
+
 class _Budget(Exception):
     pass
 
@@ -168,9 +188,10 @@ def main():
     ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
     mean_L = 2050 + (T - 1) / 2.0
     bytes_per_token = W_ELEMS * 4 + KV_ELEMS_PER_POS * (mean_L + 1) * 4
+    traffic = pmc_traffic(dom)
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"),
         "bytes_per_launch": prof[dom]["bytes"], "avg_us_per_launch": round(prof[dom]["avg_us"], 3),
         "context_len_at_measurement": 2050 + T,
         "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1),

@@ -4,13 +4,9 @@ set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for CNT in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$CNT
-  (cd /tmp && ER_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d /tmp/pmc_$CNT -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --tokens 200 > gpurun_out_pmc_$CNT.json 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$CNT.err)
+  (cd /tmp && ER_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d /tmp/pmc_$CNT -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --tokens 12 > gpurun_out_pmc_$CNT.json 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_$CNT.err)
   echo "rc=$?"; ls -la /tmp/pmc_$CNT | head -6; grep -v amdgpu.ids gpurun_out/pmc_$CNT.err | tail -4
 done
 python scripts/pmc_summary.py pmc $(find /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv") > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.err
 head -c 4000 gpurun_out/pmc_summary.json; tail -3 gpurun_out/pmc_summary.err
-# also MFMA / VALU busy for the prefill GEMM in its own pass
-rm -rf /tmp/pmc_sq; (cd /tmp && ER_NO_GRAPH=1 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --tokens 50 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.err); echo "rc=$?"
-python scripts/pmc_summary.py pmc $(find /tmp/pmc_sq -name "*counter_collection.csv") > gpurun_out/pmc_sq_summary.json 2>> gpurun_out/pmc_summary.err
-head -c 2500 gpurun_out/pmc_sq_summary.json
 du -sh gpurun_out
