@@ -95,6 +95,7 @@ struct er_ctx {
     // hipGraph of one step
     hipGraphExec_t step_exec = nullptr;
     bool use_graph = true;
+    bool batched = false;     // B > 4 (or ER_FORCE_BATCHED=1): weights streamed once per 16 rows
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
@@ -423,6 +424,8 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     c->B = batch;
     c->Lcap = Lcap;
     c->have_hidden = false;
+    const char* fb = getenv("ER_FORCE_BATCHED");
+    c->batched = batch > 4 || (fb && fb[0] == '1');
     return ER_OK;
 }
 
@@ -471,6 +474,31 @@ static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st) {
     }
 }
 
+// B > 4: weights streamed once per pass of up to 16 rows (gemv_batched_kernel)
+constexpr int NBB = 16;
+template <int PH, int RW, int EPI>
+static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) {
+    for (int b = 0; b < B; b += NBB) {
+        const int nb = (B - b) < NBB ? (B - b) : NBB;
+        GemvArgs g = a;
+        g.xin += (long long)b * K;
+        if (g.pos) g.pos += b;
+        if (g.out) g.out += (long long)b * a.N;
+        if (g.resid) g.resid += (long long)b * a.N;
+        if (g.q) g.q += (long long)b * a.hidden;
+        if (g.kcache) g.kcache += (long long)b * a.kv_bstride;
+        if (g.vcache) g.vcache += (long long)b * a.kv_bstride;
+        hipError_t e = launch_gemv_batched<float, PH, NBB, RW, EPI>(g, nb, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+template <int PRO>
+static hipError_t prep_rows(const GemvArgs& a, int B, hipStream_t st) {
+    hipLaunchKernelGGL((prep_rows_kernel<PRO>), dim3(B), dim3(ER_WG), 0, st, a);
+    return hipGetLastError();
+}
+
 static AttnDecArgs attn_args(er_ctx* c, int layer) {
     AttnDecArgs a{};
     a.q = c->qbuf;
@@ -514,9 +542,16 @@ static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, lo
             a.vcache = c->vc + (long long)layer * c->kv_lstride;
             if (layer == 0) {
                 a.embd = c->embd; a.posemb = c->posemb; a.tok = c->st.tok;
-                return gemv_rw<1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
+            } else {
+                a.xin = c->ypre; a.ln_w = c->layers[layer - 1].ln2w; a.ln_b = c->layers[layer - 1].ln2b;
             }
-            a.xin = c->ypre; a.ln_w = c->layers[layer - 1].ln2w; a.ln_b = c->layers[layer - 1].ln2b;
+            if (c->batched) {
+                hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
+                if (e != hipSuccess) return e;
+                a.xin = c->hbuf;
+                return gemv_batched_groups<1, 2, EPI_QKV>(a, B, H, st);
+            }
+            if (layer == 0) return gemv_rw<1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
             return gemv_rw<1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st);
         }
         case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, B, st);
@@ -524,22 +559,37 @@ static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, lo
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             a.W = L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
+            if (c->batched) return gemv_batched_groups<1, 1, EPI_RESID>(a, B, H, st);
             return gemv_rw<1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st);
         }
         case 4: {   // h1 = LN1(ypre1); f = relu(fc1 h1 + b)
             const LayerW& L = c->layers[layer];
             a.W = L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
             a.hout = c->h1buf; a.out = c->fbuf;
+            if (c->batched) {
+                hipError_t e = prep_rows<PRO_LN>(a, B, st);
+                if (e != hipSuccess) return e;
+                a.xin = c->h1buf;
+                return gemv_batched_groups<1, 2, EPI_RELU>(a, B, H, st);
+            }
             return gemv_rw<1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
         }
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];
             a.W = L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
+            if (c->batched) return gemv_batched_groups<4, 1, EPI_RESID>(a, B, I, st);
             return gemv_rw<4, PRO_NONE, EPI_RESID>(c->rw_fc2, a, B, I, st);
         }
         case 6: {   // logits = lm_head LN2_last(ypre)
             a.W = c->lm_head; a.bias = nullptr; a.N = g.vocab_size; a.xin = c->ypre;
             a.ln_w = c->layers[nl - 1].ln2w; a.ln_b = c->layers[nl - 1].ln2b; a.hout = nullptr; a.out = c->logits;
+            if (c->batched) {
+                a.hout = c->hbuf;
+                hipError_t e = prep_rows<PRO_LN>(a, B, st);
+                if (e != hipSuccess) return e;
+                a.xin = c->hbuf;
+                return gemv_batched_groups<1, 1, EPI_STORE>(a, B, H, st);
+            }
             return gemv_groups<1, 1, PRO_LN, EPI_STORE>(a, B, H, st);
         }
         case 7:
@@ -967,6 +1017,31 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
     a.W = w; a.bias = bias; a.N = n; a.xin = x; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.hout = xnorm_out;
     a.out = y; a.resid = resid;
     hipError_t e;
+    if (B > 4) {   // batched kernels: LayerNorm rows first (same arithmetic as the fused prologue), then one pass per 16 rows
+        float* tmp = nullptr;
+        if (ln_w) {
+            if (k != 1536) return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: LayerNorm prologue needs k=1536");
+            if (!xnorm_out) { HIPCHK(hipMalloc(&tmp, (size_t)B * k * 4)); a.hout = tmp; }
+            e = prep_rows<PRO_LN>(a, B, st);
+            if (e != hipSuccess) { if (tmp) hipFree(tmp); HIPRET(e); }
+            a.xin = a.hout;
+        }
+        if (k == 1536) {
+            if (relu && !resid) e = gemv_batched_groups<1, 2, EPI_RELU>(a, B, k, st);
+            else if (!relu && !resid) e = gemv_batched_groups<1, 1, EPI_STORE>(a, B, k, st);
+            else if (!relu && resid) e = gemv_batched_groups<1, 1, EPI_RESID>(a, B, k, st);
+            else e = hipErrorInvalidValue;
+        } else if (k == 6144 && !relu && resid && !ln_w) {
+            e = gemv_batched_groups<4, 1, EPI_RESID>(a, B, k, st);
+        } else {
+            e = hipErrorInvalidValue;
+        }
+        hipError_t e2 = hipStreamSynchronize(st);
+        if (tmp) hipFree(tmp);
+        HIPRET(e);
+        HIPRET(e2);
+        return ER_OK;
+    }
     if (k == 1536) {
         if (ln_w && relu && !resid) e = gemv_groups<1, 2, PRO_LN, EPI_RELU>(a, B, k, st);
         else if (ln_w && !relu && !resid) e = gemv_groups<1, 1, PRO_LN, EPI_STORE>(a, B, k, st);

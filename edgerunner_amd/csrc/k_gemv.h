@@ -25,7 +25,7 @@ enum { PRO_NONE = 0, PRO_LN = 1, PRO_EMBED = 2 };
 enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_QKV = 3 };
 
 struct GemvArgs {
-    const float* W;        // [N][K]
+    const void* W;         // [N][K] in the kernel's weight type
     const float* bias;     // [N] or nullptr
     int N;
     // prologue
@@ -47,6 +47,27 @@ struct GemvArgs {
     int hidden, head_dim, l_cap;
     long long kv_bstride;  // H*Lcap*D
 };
+
+// Weight storage types: fp32 (exact mode) or fp16 (fast mode, fp32 accumulate).  One 16-byte load
+// carries EPL weights; the matching EPL inputs are EPL/4 consecutive float4.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <typename WT> struct WTraits;
+template <> struct WTraits<float> { static constexpr int EPL = 4; };
+template <> struct WTraits<_Float16> { static constexpr int EPL = 8; };
+
+template <typename WT>
+__device__ __forceinline__ float dot_w(const f32x4& wraw, const f32x4* x, float s) {
+    if constexpr (sizeof(WT) == 4) {
+        return dot4(wraw, x[0], s);
+    } else {
+        const f16x8 h = __builtin_bit_cast(f16x8, wraw);
+        s = fmaf((float)h[0], x[0].x, s); s = fmaf((float)h[1], x[0].y, s);
+        s = fmaf((float)h[2], x[0].z, s); s = fmaf((float)h[3], x[0].w, s);
+        s = fmaf((float)h[4], x[1].x, s); s = fmaf((float)h[5], x[1].y, s);
+        s = fmaf((float)h[6], x[1].z, s); s = fmaf((float)h[7], x[1].w, s);
+        return s;
+    }
+}
 
 // bias / residual / cache position are fetched at kernel entry (EpiPre) so that the epilogue after the
 // reduction is pure arithmetic + one store instead of a chain of dependent L2 round trips.
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         const int row = min(row0 + r, a.N - 1);            // clamp: out-of-range rows are loaded but never stored
-        const f32x4* wr = reinterpret_cast<const f32x4*>(a.W + (long long)row * K + slice * (J * 256));
+        const f32x4* wr = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.W) + (long long)row * K + slice * (J * 256));
 #pragma unroll
         for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
     }
@@ -213,6 +234,193 @@ inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(NB * K + 64) * sizeof(float);
     hipLaunchKernelGGL((gemv_f32_kernel<J, KS, NB, RW, PRO, EPI>), dim3(grid), dim3(ER_WG), lds, st, a);
     return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Batched decode (B > 4 rows): the same projections with the weights streamed ONCE per pass of NB
+// rows.  The NB input rows (already LayerNorm'd / embedded by prep_rows_kernel) sit in LDS; a wave
+// owns RW weight rows, keeps RW*NB accumulators and re-reads the inputs from LDS (ds_read_b128,
+// conflict-free) instead of holding them in registers.  Arithmetic per (row, batch-row) is kept
+// IDENTICAL to the B <= 4 kernel - same per-lane fmaf chain over the 1536-slice, same xor-32..1
+// reduction tree (done as a reduce-scatter so NB sums cost 17 shuffles instead of 6*NB), same
+// slice order for K = 6144 - so a row of a batch is bit-identical to the same row run alone.
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
+
+template <int NB> struct AccRow { float v[NB]; };
+
+template <int NB>
+__device__ __forceinline__ float reduce_scatter(AccRow<NB> a, int lane) {   // by value: keeps everything in registers
+    float (&v)[NB] = a.v;
+    constexpr int STEPS = ilog2(NB);
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        const int h = NB >> (k + 1), m = 32 >> k;      // compile-time after unrolling
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < NB / 2; ++i)
+            if (i < h) {
+                const float send = up ? v[i] : v[i + h];
+                const float keep = up ? v[i + h] : v[i];
+                v[i] = keep + __shfl_xor(send, m, 64);
+            }
+    }
+    float r = v[0];
+#pragma unroll
+    for (int k = STEPS; k < 6; ++k) r += __shfl_xor(r, 32 >> k, 64);
+    return r;
+}
+
+template <int NB>
+__device__ __forceinline__ int reduce_scatter_owner(int lane) {   // batch row whose total this lane holds
+    constexpr int STEPS = ilog2(NB);
+    int b = 0;
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) b += (lane & (32 >> k)) ? (NB >> (k + 1)) : 0;
+    return b;
+}
+
+// grid = ceil(N / (BW*RW)) workgroups of BW = 8 waves (the LDS image limits residency to one workgroup per
+// CU, so the workgroup is made as wide as the row supply allows); dynamic LDS = NB*1536 floats.  PH = K / 1536 slices.
+constexpr int GB_WAVES = 8, GB_THREADS = GB_WAVES * 64;
+template <typename WT, int PH, int NB, int RW, int EPI>
+__global__ __launch_bounds__(GB_THREADS) void gemv_batched_kernel(GemvArgs a, int nb_valid) {
+    constexpr int EPL = WTraits<WT>::EPL, SL = 1536, J = SL / (64 * EPL), XV = EPL / 4, K = PH * SL;
+    constexpr int OWN = 64 / NB;               // lanes per owner group after the reduce-scatter
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [NB][SL]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int row0 = (blockIdx.x * GB_WAVES + wid) * RW;
+
+    // weights: the current 1536-slice in registers, the next slice prefetched while this one is consumed
+    const f32x4* wrow[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+        wrow[r] = reinterpret_cast<const f32x4*>(reinterpret_cast<const WT*>(a.W) + (long long)min(row0 + r, a.N - 1) * K);
+    f32x4 wc[RW][J], wn[RW][J];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int j = 0; j < J; ++j) wc[r][j] = __builtin_nontemporal_load(wrow[r] + j * 64 + lane);
+    const int b_own = reduce_scatter_owner<NB>(lane);
+    const bool owner = (lane & (OWN - 1)) == 0 && b_own < nb_valid;
+    EpiPre pre[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) pre[r] = gemv_epi_prefetch<EPI>(a, row0 + r, min(b_own, nb_valid - 1));
+
+    float total[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) total[r] = 0.f;
+#pragma unroll 1
+    for (int ph = 0; ph < PH; ++ph) {      // a real loop: unrolling the phases lets the scheduler pile up 4x the live values
+        if (ph > 0) __syncthreads();
+        // keep each slice's staging loads inside its own phase (hoisting all PH fills to the top spills)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph + 1 < PH) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int j = 0; j < J; ++j) wn[r][j] = __builtin_nontemporal_load(wrow[r] + ((ph + 1) * J + j) * 64 + lane);
+        }
+        {   // stage the nb_valid input rows of this slice: independent loads issued in batches of 8, then
+            // written (rows >= nb_valid stay uninitialised: their accumulators are never stored)
+            constexpr int PER_ROW = SL / 4, FILL = NB * PER_ROW / GB_THREADS;   // float4 per thread (12 at NB = 16)
+            static_assert(NB * PER_ROW % GB_THREADS == 0 && FILL % 4 == 0, "fill loop shape");
+#pragma unroll
+            for (int i0 = 0; i0 < FILL; i0 += 4) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid + (i0 + u) * GB_THREADS;
+                    const int b = i / PER_ROW, c = i - b * PER_ROW;
+                    // unconditional load from a clamped row: a per-element branch would serialise the loads
+                    v[u] = reinterpret_cast<const f32x4*>(a.xin + (long long)min(b, nb_valid - 1) * K + ph * SL)[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4*>(xs)[tid + (i0 + u) * GB_THREADS] = v[u];
+            }
+        }
+        __syncthreads();
+        AccRow<NB> acc[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[r].v[b] = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                f32x4 x[XV];
+#pragma unroll
+                for (int u = 0; u < XV; ++u) x[u] = reinterpret_cast<const f32x4*>(xs + b * SL)[(j * 64 + lane) * XV + u];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc[r].v[b] = dot_w<WT>(wc[r][j], x, acc[r].v[b]);
+            }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) total[r] += reduce_scatter<NB>(acc[r], lane);
+        if (ph + 1 < PH) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int j = 0; j < J; ++j) wc[r][j] = wn[r][j];
+        }
+    }
+    if (owner) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (row0 + r < a.N) gemv_epilogue<EPI>(a, row0 + r, b_own, total[r], pre[r]);
+    }
+}
+
+template <typename WT, int PH, int NB, int RW, int EPI>
+inline hipError_t launch_gemv_batched(const GemvArgs& a, int nb_valid, hipStream_t st) {
+    const int grid = (a.N + GB_WAVES * RW - 1) / (GB_WAVES * RW);
+    const size_t lds = (size_t)NB * 1536 * sizeof(float);
+    static bool configured = false;
+    if (!configured) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_batched_kernel<WT, PH, NB, RW, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemv_batched_kernel<WT, PH, NB, RW, EPI>), dim3(grid), dim3(GB_THREADS), lds, st, a, nb_valid);
+    return hipGetLastError();
+}
+
+// One workgroup per batch row: the LayerNorm / embedding prologue of gemv_f32_kernel as its own kernel
+// (identical thread->element mapping and reduction order), writing the GEMV input / residual row.
+template <int PRO>
+__global__ __launch_bounds__(ER_WG) void prep_rows_kernel(GemvArgs a) {
+    constexpr int K = 1536, PT = K / ER_WG;
+    __shared__ float red[8];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    float v[PT];
+    if (PRO == PRO_EMBED) {
+        const float* e = a.embd + (long long)a.tok[b] * K;
+        const float* p = a.posemb + (long long)a.pos[b] * K;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) v[i] = e[tid + i * ER_WG] + p[tid + i * ER_WG];
+    } else {
+        const float* x = a.xin + (long long)b * K;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) v[i] = x[tid + i * ER_WG];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) s += v[i];
+        const float mean = block_sum(s, red) / (float)K;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { const float d = v[i] - mean; s2 = fmaf(d, d, s2); }
+        const float var = block_sum(s2, red) / (float)K;
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = tid + i * ER_WG;
+            v[i] = (v[i] - mean) * rstd * a.ln_w[c] + a.ln_b[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * ER_WG] = v[i];
 }
 
 }  // namespace er

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Aggregate decode throughput at batch B (independent clouds, greedy, EOS suppressed) on one GPU.
+BASELINE configs[2]/[3] shapes: B=32, T=4*num_face.  Usage: bench_batch.py B T [num_face]"""
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from edgerunner_amd import weights as W  # noqa: E402
+from edgerunner_amd.models import LMM  # noqa: E402
+from edgerunner_amd.options import config_defaults  # noqa: E402
+
+
+def main():
+    Bs = [int(x) for x in sys.argv[1].split(",")]
+    T = int(sys.argv[2])
+    nf = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=24, generate_mode="greedy")
+    lmm = LMM(opt, "cuda:0")
+    lmm.mesh_decoder.load_state_iter(W.iter_state_dict(opt, 0, "perturbed"), strict=True)
+    for B in Bs:
+        pcs = torch.cat([W.synthetic_point_cloud(i, 4096) for i in range(B)]).to("cuda:0")
+        t0 = time.perf_counter()
+        _, toks = lmm.generate(pcs, nf, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms = lmm.mesh_decoder.last_decode_ms
+        mean_L = 2050 + (T - 1) / 2
+        bytes_step = 680_752_128 * 4 + B * 73_728 * (mean_L + 1) * 4
+        print(json.dumps({"B": B, "T": T, "decode_ms": round(ms, 1), "ms_per_step": round(ms / T, 3),
+                          "aggregate_tok_s": round(B * T / ms * 1e3, 1), "end_to_end_tok_s": round(B * T / wall, 1),
+                          "algorithmic_GBps": round(bytes_step / (ms / T * 1e-3) / 1e9, 1),
+                          }), flush=True)
+        prof = lmm.mesh_decoder.profile_decode_kernels(repeats=2)
+        print("   per-kind us:", {k: round(v["avg_us"], 1) for k, v in prof.items()}, flush=True)
+
+
+if __name__ == "__main__":
+    main()

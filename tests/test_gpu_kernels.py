@@ -68,6 +68,35 @@ def test_gemv_fc2_ksplit_resid(B):
     close(y, x.double() @ w.double().T + b.double() + r.double(), 4e-6, 1e-5, "fc2")
 
 
+@pytest.mark.parametrize("B", [5, 16, 19])
+def test_gemv_batched_rows_bit_identical_to_single(B):
+    """B > 4 takes the batched kernels (weights streamed once per 16 rows): every row must equal,
+    bit for bit, the same row pushed through the B = 1 kernel (same fmaf chains and reduction tree)."""
+    from edgerunner_amd import kernels as K
+    w1, b1 = rnd(6144, 1536, seed=60, scale=0.02), rnd(6144, seed=61, scale=0.02)
+    w2, b2 = rnd(1536, 6144, seed=62, scale=0.02), rnd(1536, seed=63, scale=0.02)
+    wh = rnd(518, 1536, seed=64, scale=0.02)
+    x = rnd(B, 1536, seed=65) * 2 + 0.3
+    lw, lb = 1 + 0.1 * rnd(1536, seed=66), 0.05 * rnd(1536, seed=67)
+    r = rnd(B, 1536, seed=68)
+    f, xn = K.gemv(w1, x, b1, lw, lb, relu=True, return_xnorm=True)          # fc1-like: LN + ReLU
+    y = K.gemv(w2, f, b2, resid=r)                                             # fc2-like: K = 6144 + residual
+    lg = K.gemv(wh, x, None, lw, lb)                                           # lm_head-like: ragged N
+    o = K.gemv(w2[:, :1536].contiguous(), x, b2, resid=r)                      # out_proj-like
+    xr = torch.nn.functional.layer_norm(x.double(), (1536,), lw.double(), lb.double(), 1e-5)
+    close(f, torch.relu(xr @ w1.double().T + b1.double()), 2e-6, 1e-5, "batched fc1")
+    close(y, f.double() @ w2.double().T + b2.double() + r.double(), 4e-6, 1e-5, "batched fc2")
+    for i in range(B):
+        f1, xn1 = K.gemv(w1, x[i:i + 1].contiguous(), b1, lw, lb, relu=True, return_xnorm=True)
+        assert torch.equal(xn1[0], xn[i]), f"LayerNorm row {i} differs from the fused prologue"
+        assert torch.equal(f1[0], f[i]), f"fc1 row {i}"
+        y1 = K.gemv(w2, f[i:i + 1].contiguous(), b2, resid=r[i:i + 1].contiguous())
+        assert torch.equal(y1[0], y[i]), f"fc2 row {i}"
+        assert torch.equal(K.gemv(wh, x[i:i + 1].contiguous(), None, lw, lb)[0], lg[i]), f"head row {i}"
+        assert torch.equal(K.gemv(w2[:, :1536].contiguous(), x[i:i + 1].contiguous(), b2, resid=r[i:i + 1].contiguous())[0],
+                           o[i]), f"out_proj row {i}"
+
+
 # ------------------------------------------------------------------ decode attention
 @pytest.mark.parametrize("D,lens,steps", [(96, [2051], 4), (96, [1, 33], 4), (96, [6049, 4000, 17], 4),
                                           (64, [300], 4), (96, [2050, 129], 2), (96, [2050, 255, 256, 257], 8)])

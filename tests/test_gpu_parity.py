@@ -203,6 +203,22 @@ def test_batch_rows_bit_identical_to_single(gold_small):
     assert_ids(toks[1], single[0], "row 1 vs its single-sample run")
 
 
+def test_batch18_two_passes_and_forced_batched_single(gold_small, monkeypatch):
+    """B = 18 -> a full pass of 16 rows + a ragged pass of 2; and the batched kernels forced at B = 1."""
+    lmm = make_lmm()
+    batch = torch.cat([cloud(i % 3) for i in range(18)])
+    _, toks = lmm.generate(batch, 1000, tokenizer=object(), max_new_tokens=40, min_new_tokens=40)
+    for r in range(0, 18, 3):
+        assert_ids(toks[r], gold_small["ids_min96"][0][:40], f"row {r} of an 18-row batch")
+    assert_ids(toks[1], toks[16], "rows 1 and 16 hold the same cloud")
+    monkeypatch.setenv("ER_FORCE_BATCHED", "1")
+    lmm.mesh_decoder.reserve(1, 4096)      # re-reserve so the context re-reads the switch
+    _, t1 = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
+    assert_ids(t1[0], gold_small["ids_min96"][0], "batched kernels at B = 1")
+    monkeypatch.delenv("ER_FORCE_BATCHED")
+    lmm.mesh_decoder.reserve(1, 4097)
+
+
 # ------------------------------------------------------------------ graph replay == eager launches
 def test_graph_replay_equals_eager(gold_small, monkeypatch):
     monkeypatch.setenv("ER_NO_GRAPH", "1")
