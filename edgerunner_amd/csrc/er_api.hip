@@ -48,6 +48,9 @@ static int fail(int code, const char* fmt, ...) {
 
 // ------------------------------------------------------------------------------------ context
 struct LayerW {
+    // fast mode (fp16 storage): *_h hold the streamed fp16 matrices; the fp32 copies then hold the SAME
+    // fp16-rounded values (used by the prefill GEMMs), so prefill and decode see one model
+    _Float16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;
     float *wqkv = nullptr, *bqkv = nullptr;   // fused [3*hidden][hidden] in q,k,v order
     float *wo = nullptr, *bo = nullptr, *ln1w = nullptr, *ln1b = nullptr;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *ln2w = nullptr, *ln2b = nullptr;
@@ -66,6 +69,8 @@ struct er_ctx {
     // weights
     std::vector<LayerW> layers;
     float *embd = nullptr, *posemb = nullptr, *lm_head = nullptr, *embed_num_face = nullptr;
+    _Float16* lm_head_h = nullptr;
+    bool fast = false;       // fp16 weights + fp16 KV cache, fp32 accumulate
     float *proj_w = nullptr, *proj_b = nullptr, *normc_w = nullptr, *normc_b = nullptr;
     // point encoder
     float *pe_query = nullptr, *pe_basis = nullptr, *pe_mlp_w = nullptr, *pe_mlp_b = nullptr, *pe_ln_w = nullptr,
@@ -79,7 +84,8 @@ struct er_ctx {
     std::vector<void*> owned;           // every hipMalloc'd weight block
     // KV cache
     int B = 0, Lcap = 0, S_splits = 0;
-    float *kc = nullptr, *vc = nullptr;       // [layers][B][H][Lcap][D]
+    void *kc = nullptr, *vc = nullptr;        // [layers][B][H][Lcap][D], fp32 or fp16 (fast)
+    int kv_esz = 4;
     long long kv_bstride = 0, kv_lstride = 0;
     // decode workspace ([B][...])
     float *ypre = nullptr, *hbuf = nullptr, *ypre1 = nullptr, *h1buf = nullptr, *qbuf = nullptr, *abuf = nullptr,
@@ -100,7 +106,7 @@ struct er_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
-    Buf p_h, p_q, p_a, p_y, p_f, p_sc, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp;
+    Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp;
 };
 
 static int ensure(Buf& b, size_t n) {
@@ -174,8 +180,10 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     if (cfg->num_heads <= 0 || cfg->hidden_dim % cfg->num_heads) return fail(ER_ERR_INVALID, "hidden_dim %% num_heads != 0");
     const int D = cfg->hidden_dim / cfg->num_heads;
     if (D != 96 && D != 64) return fail(ER_ERR_UNSUPPORTED, "head_dim %d not built (96, 64)", D);
-    if (cfg->weight_dtype != ER_F32 || cfg->kv_dtype != ER_F32)
-        return fail(ER_ERR_UNSUPPORTED, "only fp32 weights / fp32 KV (exact mode) are built in this round");
+    const bool exact = cfg->weight_dtype == ER_F32 && cfg->kv_dtype == ER_F32;
+    const bool fast = cfg->weight_dtype == ER_F16 && cfg->kv_dtype == ER_F16;
+    if (!exact && !fast)
+        return fail(ER_ERR_UNSUPPORTED, "built modes: fp32 weights + fp32 KV (exact) or fp16 weights + fp16 KV (fast)");
     if (cfg->vocab_size > 1024) return fail(ER_ERR_UNSUPPORTED, "vocab_size > 1024");
     if (cfg->cond_mode == ER_COND_POINT && (cfg->point_hidden_dim != 1024 || cfg->point_hidden_dim % cfg->point_num_heads))
         return fail(ER_ERR_UNSUPPORTED, "point encoder width %d not built (1024)", cfg->point_hidden_dim);
@@ -184,6 +192,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->cfg = *cfg;
     c->device = device;
     c->D = D;
+    c->fast = fast;
+    c->kv_esz = fast ? 2 : 4;
     c->layers.resize(cfg->num_layers);
     const char* ng = getenv("ER_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
@@ -204,7 +214,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
 }
 
 static void free_kv(er_ctx* c) {
-    for (float* p : {c->kc, c->vc, c->ypre, c->hbuf, c->ypre1, c->h1buf, c->qbuf, c->abuf, c->fbuf, c->logits, c->part})
+    for (void* p : {c->kc, c->vc, (void*)c->ypre, (void*)c->hbuf, (void*)c->ypre1, (void*)c->h1buf, (void*)c->qbuf,
+                    (void*)c->abuf, (void*)c->fbuf, (void*)c->logits, (void*)c->part})
         if (p) hipFree(p);
     c->kc = c->vc = c->ypre = c->hbuf = c->ypre1 = c->h1buf = c->qbuf = c->abuf = c->fbuf = c->logits = c->part = nullptr;
     if (c->state_block) hipFree(c->state_block);
@@ -224,7 +235,7 @@ extern "C" int er_destroy(er_ctx* c) {
     hipDeviceSynchronize();
     free_kv(c);
     for (void* p : c->owned) hipFree(p);
-    for (Buf* b : {&c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
+    for (Buf* b : {&c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->p_qkv, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
                    &c->e_q, &c->e_sc, &c->e_att, &c->e_l, &c->e_ln, &c->e_u, &c->e_g, &c->e_lat, &c->e_tmp})
         if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -297,6 +308,23 @@ extern "C" int er_load_tensor(er_ctx* c, const char* key_c, const void* data, in
         HIPCHK(hipMemcpy(*dst, h.data(), want * 4, hipMemcpyHostToDevice));
         return 0;
     };
+    // streamed decoder matrix: fp32 copy (+ fp16 copy and fp16-rounded fp32 values in fast mode)
+    auto put_w = [&](float** dst, _Float16** dst_h, size_t total, size_t off, size_t want) -> int {
+        ERCHK(expect(want));
+        if (!*dst) { ERCHK(dev_alloc(c, dst, total)); HIPCHK(hipMemset(*dst, 0, total * 4)); }
+        if (c->fast) {
+            std::vector<_Float16> hh(want);
+            for (size_t i = 0; i < want; ++i) { hh[i] = (_Float16)h[i]; h[i] = (float)hh[i]; }
+            if (!*dst_h) {
+                HIPCHK(hipMalloc((void**)dst_h, total * 2));
+                c->owned.push_back(*dst_h);
+                HIPCHK(hipMemset(*dst_h, 0, total * 2));
+            }
+            HIPCHK(hipMemcpy(*dst_h + off, hh.data(), want * 2, hipMemcpyHostToDevice));
+        }
+        HIPCHK(hipMemcpy(*dst + off, h.data(), want * 4, hipMemcpyHostToDevice));
+        return 0;
+    };
     auto put_at = [&](float** dst, size_t total, size_t off, size_t want) -> int {   // slice of a fused block
         ERCHK(expect(want));
         if (!*dst) { ERCHK(dev_alloc(c, dst, total)); HIPCHK(hipMemset(*dst, 0, total * 4)); }
@@ -313,26 +341,26 @@ extern "C" int er_load_tensor(er_ctx* c, const char* key_c, const void* data, in
         LayerW& L = c->layers[li];
         const std::string rest = key.substr(dot + 1);
         const size_t HH = (size_t)H * H;
-        if (rest == "self_attn.q_proj.weight") rc = put_at(&L.wqkv, 3 * HH, 0, HH);
-        else if (rest == "self_attn.k_proj.weight") rc = put_at(&L.wqkv, 3 * HH, HH, HH);
-        else if (rest == "self_attn.v_proj.weight") rc = put_at(&L.wqkv, 3 * HH, 2 * HH, HH);
+        if (rest == "self_attn.q_proj.weight") rc = put_w(&L.wqkv, &L.wqkv_h, 3 * HH, 0, HH);
+        else if (rest == "self_attn.k_proj.weight") rc = put_w(&L.wqkv, &L.wqkv_h, 3 * HH, HH, HH);
+        else if (rest == "self_attn.v_proj.weight") rc = put_w(&L.wqkv, &L.wqkv_h, 3 * HH, 2 * HH, HH);
         else if (rest == "self_attn.q_proj.bias") rc = put_at(&L.bqkv, 3 * H, 0, H);
         else if (rest == "self_attn.k_proj.bias") rc = put_at(&L.bqkv, 3 * H, H, H);
         else if (rest == "self_attn.v_proj.bias") rc = put_at(&L.bqkv, 3 * H, 2 * H, H);
-        else if (rest == "self_attn.out_proj.weight") rc = put(&L.wo, HH);
+        else if (rest == "self_attn.out_proj.weight") rc = put_w(&L.wo, &L.wo_h, HH, 0, HH);
         else if (rest == "self_attn.out_proj.bias") rc = put(&L.bo, H);
         else if (rest == "self_attn_layer_norm.weight") rc = put(&L.ln1w, H);
         else if (rest == "self_attn_layer_norm.bias") rc = put(&L.ln1b, H);
-        else if (rest == "fc1.weight") rc = put(&L.w1, (size_t)I * H);
+        else if (rest == "fc1.weight") rc = put_w(&L.w1, &L.w1_h, (size_t)I * H, 0, (size_t)I * H);
         else if (rest == "fc1.bias") rc = put(&L.b1, I);
-        else if (rest == "fc2.weight") rc = put(&L.w2, (size_t)H * I);
+        else if (rest == "fc2.weight") rc = put_w(&L.w2, &L.w2_h, (size_t)H * I, 0, (size_t)H * I);
         else if (rest == "fc2.bias") rc = put(&L.b2, H);
         else if (rest == "final_layer_norm.weight") rc = put(&L.ln2w, H);
         else if (rest == "final_layer_norm.bias") rc = put(&L.ln2b, H);
         else return 1;
     } else if (key == "mesh_decoder.model.embd.weight") rc = put(&c->embd, (size_t)g.vocab_size * H);
     else if (key == "mesh_decoder.model.embed_positions.weight") rc = put(&c->posemb, (size_t)g.max_positions * H);
-    else if (key == "mesh_decoder.lm_head.weight") rc = put(&c->lm_head, (size_t)g.vocab_size * H);
+    else if (key == "mesh_decoder.lm_head.weight") rc = put_w(&c->lm_head, &c->lm_head_h, (size_t)g.vocab_size * H, 0, (size_t)g.vocab_size * H);
     else if (key == "embed_num_face.weight") rc = put(&c->embed_num_face, (size_t)g.num_face_buckets * H);
     else if (key == "proj_cond.weight") rc = put(&c->proj_w, (size_t)H * g.point_latent_dim);
     else if (key == "proj_cond.bias") rc = put(&c->proj_b, H);
@@ -399,10 +427,10 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     c->kv_bstride = (long long)H * Lcap * D;
     c->kv_lstride = c->kv_bstride * batch;
     const size_t kv_elems = (size_t)c->kv_lstride * g.num_layers;
-    HIPCHK(hipMalloc(&c->kc, kv_elems * 4));
-    HIPCHK(hipMalloc(&c->vc, kv_elems * 4));
+    HIPCHK(hipMalloc(&c->kc, kv_elems * c->kv_esz));
+    HIPCHK(hipMalloc(&c->vc, kv_elems * c->kv_esz));
     // decode attention: one workgroup per (row, head, chunk of 32*steps keys)
-    const int S = attn_num_chunks(Lcap, c->attn_steps);
+    const int S = attn_num_chunks(Lcap, attn_chunk(c->attn_steps, c->fast));
     c->S_splits = S;
     const size_t b = (size_t)batch;
     HIPCHK(hipMalloc(&c->ypre, b * hid * 4));
@@ -436,7 +464,7 @@ struct StepPlan {   // which kinds to launch (profiling launches one kind at a t
     int only_layer = -1;
 };
 
-template <int KS, int RW, int PRO, int EPI>
+template <typename WT, int KS, int RW, int PRO, int EPI>
 static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
     // rows are processed in groups of 4/2/1 (K = 6144 keeps <= 2 rows of input in LDS)
     const int maxnb = (KS == 1) ? 4 : 2;
@@ -453,30 +481,35 @@ static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
         if (g.out) g.out += (long long)b * a.N;
         if (g.resid) g.resid += (long long)b * a.N;
         if (g.q) g.q += (long long)b * a.hidden;
-        if (g.kcache) g.kcache += (long long)b * a.kv_bstride;
-        if (g.vcache) g.vcache += (long long)b * a.kv_bstride;
+        const long long kvb = (long long)b * a.kv_bstride * (a.kv_half ? 2 : 4);
+        if (g.kcache) g.kcache = (char*)g.kcache + kvb;
+        if (g.vcache) g.vcache = (char*)g.vcache + kvb;
         hipError_t e;
-        if (nb == 4) e = launch_gemv<6, KS, (KS == 1 ? 4 : 2), RW, PRO, EPI>(g, st);
-        else if (nb == 2) e = launch_gemv<6, KS, 2, RW, PRO, EPI>(g, st);
-        else e = launch_gemv<6, KS, 1, RW, PRO, EPI>(g, st);
+        if (nb == 4) e = launch_gemv<WT, KS, (KS == 1 ? 4 : 2), RW, PRO, EPI>(g, st);
+        else if (nb == 2) e = launch_gemv<WT, KS, 2, RW, PRO, EPI>(g, st);
+        else e = launch_gemv<WT, KS, 1, RW, PRO, EPI>(g, st);
         if (e != hipSuccess) return e;
         b += nb;
     }
     return hipSuccess;
 }
 
-template <int KS, int PRO, int EPI>
+template <typename WT, int KS, int PRO, int EPI>
 static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st) {
-    switch (rw) {
-        case 1: return gemv_groups<KS, 1, PRO, EPI>(a, B, K, st);
-        case 4: return gemv_groups<KS, 4, PRO, EPI>(a, B, K, st);
-        default: return gemv_groups<KS, 2, PRO, EPI>(a, B, K, st);
+    if constexpr (sizeof(WT) == 2) {     // fp16 rows are half as long: twice the rows per wave keeps the bytes in flight
+        return rw >= 2 ? gemv_groups<WT, KS, 4, PRO, EPI>(a, B, K, st) : gemv_groups<WT, KS, 2, PRO, EPI>(a, B, K, st);
+    } else {
+        switch (rw) {
+            case 1: return gemv_groups<WT, KS, 1, PRO, EPI>(a, B, K, st);
+            case 4: return gemv_groups<WT, KS, 4, PRO, EPI>(a, B, K, st);
+            default: return gemv_groups<WT, KS, 2, PRO, EPI>(a, B, K, st);
+        }
     }
 }
 
 // B > 4: weights streamed once per pass of up to 16 rows (gemv_batched_kernel)
 constexpr int NBB = 16;
-template <int PH, int RW, int EPI>
+template <typename WT, int PH, int RW, int EPI>
 static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) {
     for (int b = 0; b < B; b += NBB) {
         const int nb = (B - b) < NBB ? (B - b) : NBB;
@@ -486,9 +519,10 @@ static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) 
         if (g.out) g.out += (long long)b * a.N;
         if (g.resid) g.resid += (long long)b * a.N;
         if (g.q) g.q += (long long)b * a.hidden;
-        if (g.kcache) g.kcache += (long long)b * a.kv_bstride;
-        if (g.vcache) g.vcache += (long long)b * a.kv_bstride;
-        hipError_t e = launch_gemv_batched<float, PH, NBB, RW, EPI>(g, nb, st);
+        const long long kvb = (long long)b * a.kv_bstride * (a.kv_half ? 2 : 4);
+        if (g.kcache) g.kcache = (char*)g.kcache + kvb;
+        if (g.vcache) g.vcache = (char*)g.vcache + kvb;
+        hipError_t e = launch_gemv_batched<WT, PH, NBB, RW, EPI>(g, nb, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -502,8 +536,9 @@ static hipError_t prep_rows(const GemvArgs& a, int B, hipStream_t st) {
 static AttnDecArgs attn_args(er_ctx* c, int layer) {
     AttnDecArgs a{};
     a.q = c->qbuf;
-    a.kcache = c->kc + (long long)layer * c->kv_lstride;
-    a.vcache = c->vc + (long long)layer * c->kv_lstride;
+    a.kcache = (char*)c->kc + (long long)layer * c->kv_lstride * c->kv_esz;
+    a.vcache = (char*)c->vc + (long long)layer * c->kv_lstride * c->kv_esz;
+    a.chunk = attn_chunk(c->attn_steps, c->fast);
     a.pos = c->st.pos;
     a.fixed_len = 0;
     a.len_dev = nullptr;
@@ -518,28 +553,30 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     return a;
 }
 
-static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int steps, int B, hipStream_t st) {
-    return D == 96 ? launch_attn_partial_d<96>(a, steps, B, st) : launch_attn_partial_d<64>(a, steps, B, st);
+static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int steps, bool kv_half, int B, hipStream_t st) {
+    return D == 96 ? launch_attn_partial_d<96>(a, steps, kv_half, B, st) : launch_attn_partial_d<64>(a, steps, kv_half, B, st);
 }
-static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int steps, int B, hipStream_t st) {
-    return D == 96 ? launch_attn_combine_d<96>(a, steps, B, st) : launch_attn_combine_d<64>(a, steps, B, st);
+static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int B, hipStream_t st) {
+    return D == 96 ? launch_attn_combine_d<96>(a, B, st) : launch_attn_combine_d<64>(a, B, st);
 }
 
-static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, long long* out_ids, int out_ld) {
+template <typename WT>
+static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, long long* out_ids, int out_ld) {
+    constexpr bool HALF = sizeof(WT) == 2;
     const er_config& g = c->cfg;
     const int H = g.hidden_dim, I = g.intermediate_dim, B = c->B;
     const int nl = g.num_layers;
     GemvArgs a{};
     a.eps = g.ln_eps;
-    a.hidden = H; a.head_dim = c->D; a.l_cap = c->Lcap; a.kv_bstride = c->kv_bstride;
+    a.hidden = H; a.head_dim = c->D; a.l_cap = c->Lcap; a.kv_bstride = c->kv_bstride; a.kv_half = HALF ? 1 : 0;
     switch (kind) {
         case 0: {   // qkv
             const LayerW& L = c->layers[layer];
-            a.W = L.wqkv; a.bias = L.bqkv; a.N = 3 * H;
+            a.W = HALF ? (const void*)L.wqkv_h : (const void*)L.wqkv; a.bias = L.bqkv; a.N = 3 * H;
             a.hout = c->hbuf; a.pos = c->st.pos;
             a.q = c->qbuf;
-            a.kcache = c->kc + (long long)layer * c->kv_lstride;
-            a.vcache = c->vc + (long long)layer * c->kv_lstride;
+            a.kcache = (char*)c->kc + (long long)layer * c->kv_lstride * c->kv_esz;
+            a.vcache = (char*)c->vc + (long long)layer * c->kv_lstride * c->kv_esz;
             if (layer == 0) {
                 a.embd = c->embd; a.posemb = c->posemb; a.tok = c->st.tok;
             } else {
@@ -549,48 +586,48 @@ static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, lo
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->hbuf;
-                return gemv_batched_groups<1, 2, EPI_QKV>(a, B, H, st);
+                return gemv_batched_groups<WT, 1, 2, EPI_QKV>(a, B, H, st);
             }
-            if (layer == 0) return gemv_rw<1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
-            return gemv_rw<1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st);
+            if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
+            return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st);
         }
-        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, B, st);
-        case 2: return launch_attn_combine(attn_args(c, layer), c->D, c->attn_steps, B, st);
+        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st);
+        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
-            a.W = L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
-            if (c->batched) return gemv_batched_groups<1, 1, EPI_RESID>(a, B, H, st);
-            return gemv_rw<1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st);
+            a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
+            if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
+            return gemv_rw<WT, 1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st);
         }
         case 4: {   // h1 = LN1(ypre1); f = relu(fc1 h1 + b)
             const LayerW& L = c->layers[layer];
-            a.W = L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
+            a.W = HALF ? (const void*)L.w1_h : (const void*)L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
             a.hout = c->h1buf; a.out = c->fbuf;
             if (c->batched) {
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->h1buf;
-                return gemv_batched_groups<1, 2, EPI_RELU>(a, B, H, st);
+                return gemv_batched_groups<WT, 1, 2, EPI_RELU>(a, B, H, st);
             }
-            return gemv_rw<1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
+            return gemv_rw<WT, 1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
         }
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];
-            a.W = L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
-            if (c->batched) return gemv_batched_groups<4, 1, EPI_RESID>(a, B, I, st);
-            return gemv_rw<4, PRO_NONE, EPI_RESID>(c->rw_fc2, a, B, I, st);
+            a.W = HALF ? (const void*)L.w2_h : (const void*)L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
+            if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);
+            return gemv_rw<WT, 4, PRO_NONE, EPI_RESID>(c->rw_fc2, a, B, I, st);
         }
         case 6: {   // logits = lm_head LN2_last(ypre)
-            a.W = c->lm_head; a.bias = nullptr; a.N = g.vocab_size; a.xin = c->ypre;
+            a.W = HALF ? (const void*)c->lm_head_h : (const void*)c->lm_head; a.bias = nullptr; a.N = g.vocab_size; a.xin = c->ypre;
             a.ln_w = c->layers[nl - 1].ln2w; a.ln_b = c->layers[nl - 1].ln2b; a.hout = nullptr; a.out = c->logits;
             if (c->batched) {
                 a.hout = c->hbuf;
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->hbuf;
-                return gemv_batched_groups<1, 1, EPI_STORE>(a, B, H, st);
+                return gemv_batched_groups<WT, 1, 1, EPI_STORE>(a, B, H, st);
             }
-            return gemv_groups<1, 1, PRO_LN, EPI_STORE>(a, B, H, st);
+            return gemv_rw<WT, 1, PRO_LN, EPI_STORE>(1, a, B, H, st);
         }
         case 7:
             hipLaunchKernelGGL(sample_head_kernel, dim3(B), dim3(ER_WG), sample_head_lds(g.vocab_size), st, c->logits,
@@ -598,6 +635,11 @@ static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, lo
             return hipGetLastError();
     }
     return hipErrorInvalidValue;
+}
+
+static hipError_t launch_kind(er_ctx* c, int kind, int layer, hipStream_t st, long long* out_ids, int out_ld) {
+    return c->fast ? launch_kind_t<_Float16>(c, kind, layer, st, out_ids, out_ld)
+                   : launch_kind_t<float>(c, kind, layer, st, out_ids, out_ld);
 }
 
 static hipError_t enqueue_layers(er_ctx* c, hipStream_t st) {
@@ -776,19 +818,35 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
     HIPRET(hipGetLastError());
     for (int l = 0; l < g.num_layers; ++l) {
         const LayerW& L = c->layers[l];
-        float* kc = c->kc + (long long)l * c->kv_lstride;
-        float* vc = c->vc + (long long)l * c->kv_lstride;
-        // q,k,v projections; k,v go straight into the cache layout      modeling_opt.py:185-196
-        GemmArgs qa = gemm_args_default();
-        qa.A = h; qa.lda = H; qa.B = L.wqkv; qa.ldb = H; qa.bias = L.bqkv; qa.C = q; qa.ldc = H;
-        qa.M = M; qa.N = 3 * H; qa.K = H; qa.epi = GEPI_QKV;
-        qa.q = q; qa.kcache = kc; qa.vcache = vc; qa.S = S; qa.hidden = H; qa.head_dim = D; qa.l_cap = c->Lcap;
-        qa.kv_bstride = c->kv_bstride;
-        HIPRET(launch_gemm(qa, 1, st));
-        for (int b = 0; b < B; ++b)   // causal attention over the prefix     modeling_opt.py:229
-            ERCHK(attention_full(q + (size_t)b * S * H, H, kc + b * c->kv_bstride, D, (long long)c->Lcap * D,
-                                 vc + b * c->kv_bstride, D, (long long)c->Lcap * D, a + (size_t)b * S * H, H, c->p_sc.p, NH, D, S,
-                                 S, true, st));
+        char* kc = (char*)c->kc + (long long)l * c->kv_lstride * c->kv_esz;
+        char* vc = (char*)c->vc + (long long)l * c->kv_lstride * c->kv_esz;
+        if (!c->fast) {
+            // q,k,v projections; k,v go straight into the cache layout      modeling_opt.py:185-196
+            GemmArgs qa = gemm_args_default();
+            qa.A = h; qa.lda = H; qa.B = L.wqkv; qa.ldb = H; qa.bias = L.bqkv; qa.C = q; qa.ldc = H;
+            qa.M = M; qa.N = 3 * H; qa.K = H; qa.epi = GEPI_QKV;
+            qa.q = q; qa.kcache = (float*)kc; qa.vcache = (float*)vc; qa.S = S; qa.hidden = H; qa.head_dim = D; qa.l_cap = c->Lcap;
+            qa.kv_bstride = c->kv_bstride;
+            HIPRET(launch_gemm(qa, 1, st));
+            for (int b = 0; b < B; ++b)   // causal attention over the prefix     modeling_opt.py:229
+                ERCHK(attention_full(q + (size_t)b * S * H, H, (float*)kc + b * c->kv_bstride, D, (long long)c->Lcap * D,
+                                     (float*)vc + b * c->kv_bstride, D, (long long)c->Lcap * D, a + (size_t)b * S * H, H,
+                                     c->p_sc.p, NH, D, S, S, true, st));
+        } else {
+            // fast mode: fused projection into fp32 scratch [M][3H]; K/V rounded to the cache dtype (fp16) both in
+            // the cache and in the scratch the prefix attention reads
+            ERCHK(ensure(c->p_qkv, (size_t)M * 3 * H));
+            float* qkv = c->p_qkv.p;
+            HIPRET(linear(h, H, L.wqkv, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
+            hipLaunchKernelGGL(kv_scatter_half_kernel, dim3(ew_grid((long long)M * 2 * H)), dim3(ER_WG), 0, st, qkv,
+                               (_Float16*)kc, (_Float16*)vc, M, S, H, D, c->Lcap, c->kv_bstride);
+            HIPRET(hipGetLastError());
+            for (int b = 0; b < B; ++b) {
+                float* base = qkv + (size_t)b * S * 3 * H;
+                ERCHK(attention_full(base, 3 * H, base + H, 3 * H, D, base + 2 * H, 3 * H, D, a + (size_t)b * S * H, H,
+                                     c->p_sc.p, NH, D, S, S, true, st));
+            }
+        }
         // y = h + out_proj(a); h1 = LN1(y)                               modeling_opt.py:232, 272-274
         HIPRET(linear(a, H, L.wo, L.bo, y, H, M, H, H, false, h, H, st));
         HIPRET(launch_layernorm(y, L.ln1w, L.ln1b, h, M, H, H, H, g.ln_eps, st));
@@ -960,7 +1018,7 @@ extern "C" int er_profile_decode_kernels(er_ctx* c, int repeats, float* avg_us, 
     long long* dummy_ids = nullptr;
     HIPCHK(hipMalloc(&dummy_ids, (size_t)B * 8 * sizeof(long long)));
 
-    const double w = 4.0;
+    const double w = c->fast ? 2.0 : 4.0;   // bytes per streamed weight / KV element
     bytes[0] = ((double)3 * H * H + 3 * H) * w + (double)B * (H + 3 * H) * w;
     bytes[1] = (double)B * 2.0 * len * H * w;
     bytes[2] = (double)B * g.num_heads * c->S_splits * (c->D + 2) * w + (double)B * H * w;
@@ -1027,12 +1085,12 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
             a.xin = a.hout;
         }
         if (k == 1536) {
-            if (relu && !resid) e = gemv_batched_groups<1, 2, EPI_RELU>(a, B, k, st);
-            else if (!relu && !resid) e = gemv_batched_groups<1, 1, EPI_STORE>(a, B, k, st);
-            else if (!relu && resid) e = gemv_batched_groups<1, 1, EPI_RESID>(a, B, k, st);
+            if (relu && !resid) e = gemv_batched_groups<float, 1, 2, EPI_RELU>(a, B, k, st);
+            else if (!relu && !resid) e = gemv_batched_groups<float, 1, 1, EPI_STORE>(a, B, k, st);
+            else if (!relu && resid) e = gemv_batched_groups<float, 1, 1, EPI_RESID>(a, B, k, st);
             else e = hipErrorInvalidValue;
         } else if (k == 6144 && !relu && resid && !ln_w) {
-            e = gemv_batched_groups<4, 1, EPI_RESID>(a, B, k, st);
+            e = gemv_batched_groups<float, 4, 1, EPI_RESID>(a, B, k, st);
         } else {
             e = hipErrorInvalidValue;
         }
@@ -1043,12 +1101,12 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
         return ER_OK;
     }
     if (k == 1536) {
-        if (ln_w && relu && !resid) e = gemv_groups<1, 2, PRO_LN, EPI_RELU>(a, B, k, st);
-        else if (ln_w && !relu && !resid) e = gemv_groups<1, 1, PRO_LN, EPI_STORE>(a, B, k, st);
-        else if (!ln_w && !relu && resid) e = gemv_groups<1, 1, PRO_NONE, EPI_RESID>(a, B, k, st);
+        if (ln_w && relu && !resid) e = gemv_groups<float, 1, 2, PRO_LN, EPI_RELU>(a, B, k, st);
+        else if (ln_w && !relu && !resid) e = gemv_groups<float, 1, 1, PRO_LN, EPI_STORE>(a, B, k, st);
+        else if (!ln_w && !relu && resid) e = gemv_groups<float, 1, 1, PRO_NONE, EPI_RESID>(a, B, k, st);
         else return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: combination not instantiated for k=1536");
     } else if (k == 6144) {
-        if (!ln_w && !relu && resid) e = gemv_groups<4, 2, PRO_NONE, EPI_RESID>(a, B, k, st);
+        if (!ln_w && !relu && resid) e = gemv_groups<float, 4, 2, PRO_NONE, EPI_RESID>(a, B, k, st);
         else return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: combination not instantiated for k=6144");
     } else {
         return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: k must be 1536 or 6144");
@@ -1057,12 +1115,12 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
     return ER_OK;
 }
 
-extern "C" int er_k_attn_decode(const float* q, const float* k, const float* v, const int32_t* len_host, float* out, int B,
-                                int heads, int head_dim, int l_cap, int steps, void* stream) {
+extern "C" int er_k_attn_decode(const float* q, const void* k, const void* v, const int32_t* len_host, float* out, int B,
+                                int heads, int head_dim, int l_cap, int steps, int kv_half, void* stream) {
     if (head_dim != 96 && head_dim != 64) return fail(ER_ERR_UNSUPPORTED, "head_dim %d", head_dim);
     if (steps != 2 && steps != 4 && steps != 8) return fail(ER_ERR_INVALID, "steps must be 2, 4 or 8 (chunk = 32*steps keys)");
     hipStream_t st = (hipStream_t)stream;
-    const int S = attn_num_chunks(l_cap, steps);
+    const int S = attn_num_chunks(l_cap, attn_chunk(steps, kv_half != 0));
     int* len_dev = nullptr;
     float* part = nullptr;
     HIPCHK(hipMalloc(&len_dev, B * sizeof(int)));
@@ -1070,10 +1128,10 @@ extern "C" int er_k_attn_decode(const float* q, const float* k, const float* v, 
     HIPCHK(hipMemcpy(len_dev, len_host, B * sizeof(int), hipMemcpyHostToDevice));
     AttnDecArgs a{};
     a.q = q; a.kcache = k; a.vcache = v; a.len_dev = len_dev; a.part = part; a.out = out;
-    a.H = heads; a.l_cap = l_cap; a.S = S; a.hidden = heads * head_dim;
+    a.H = heads; a.l_cap = l_cap; a.S = S; a.hidden = heads * head_dim; a.chunk = attn_chunk(steps, kv_half != 0);
     a.kv_bstride = (long long)heads * l_cap * head_dim; a.sqrt_d = sqrtf((float)head_dim);
-    hipError_t e = launch_attn_partial(a, head_dim, steps, B, st);
-    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, steps, B, st);
+    hipError_t e = launch_attn_partial(a, head_dim, steps, kv_half != 0, B, st);
+    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st);
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(len_dev);
     hipFree(part);

@@ -22,14 +22,15 @@ namespace er {
 
 struct AttnDecArgs {
     const float* q;        // [B][hidden]
-    const float* kcache;   // [B][H][Lcap][D]
-    const float* vcache;
+    const void* kcache;    // [B][H][Lcap][D], fp32 or fp16 (the kernel's KT)
+    const void* vcache;
     const int* pos;        // device, per row: index of the newest key (len = pos+1); or
     int fixed_len;         // >0: use this length for every row instead of pos
     const int* len_dev;    // optional per-row lengths (overrides pos when non-null)
     float* part;           // [B][H][S][D+2] = {m, l, o[0..D)}
     float* out;            // combine: [B][hidden]
     int H, l_cap, S, hidden;   // S = number of chunks the grid covers = ceil(l_cap / chunk)
+    int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
 };
@@ -40,59 +41,91 @@ __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
     return a.pos[b] + 1;
 }
 
-// grid (S, H, B), 256 threads; chunk = 32*STEPS keys: wave w, step i, lane group g -> key k0 + 32*i + 8*w + g.
-template <int D, int STEPS>
-__global__ __launch_bounds__(ER_WG) void attn_decode_f32_kernel(AttnDecArgs a) {
-    constexpr int NV = D / 32;   // float4 per lane per key (8 lanes per key)
-    constexpr int CHUNK = 32 * STEPS;
-    static_assert(D % 32 == 0, "head_dim must be a multiple of 32");
+// 16 bytes of a key row as EPL floats
+template <typename KT> struct KVec;
+template <> struct KVec<float> { static constexpr int EPL = 4, LPK = 8; };      // 8 lanes x NV float4 per key row
+template <> struct KVec<_Float16> { static constexpr int EPL = 8, LPK = 4; };   // 4 lanes x NV (8 x fp16) per key row
+
+template <typename KT>
+__device__ __forceinline__ void kv_unpack(const f32x4& raw, float (&f)[KVec<KT>::EPL]) {
+    if constexpr (sizeof(KT) == 4) {
+        f[0] = raw.x; f[1] = raw.y; f[2] = raw.z; f[3] = raw.w;
+    } else {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 h = __builtin_bit_cast(h8, raw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+    }
+}
+
+// grid (S, H, B), 256 threads.  LPK lanes cover one key row with NV 16-byte loads each (full 128-byte
+// lines per wave-instruction); a wave step covers 64/LPK keys, the workgroup chunk is 4*STEPS*(64/LPK) keys:
+// wave w, step i, lane group g -> key k0 + KPS*i + KPW*w + g.
+template <typename KT, int D, int STEPS>
+__global__ __launch_bounds__(ER_WG) void attn_decode_kernel(AttnDecArgs a) {
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
+    constexpr int NV = D / (EPL * LPK);        // 16-byte loads per lane per key
+    constexpr int KPW = 64 / LPK;              // keys per wave step
+    constexpr int KPS = ER_NWAVES * KPW;       // keys per workgroup step
+    constexpr int CHUNK = KPS * STEPS;
+    static_assert(D % (EPL * LPK) == 0, "head_dim must tile into 16-byte loads");
     __shared__ __attribute__((aligned(16))) float ored[ER_NWAVES * D];
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int p = lane & 7, g = lane >> 3;
+    const int p = lane & (LPK - 1), g = lane / LPK;
     const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int len = attn_len(a, b);
     const int k0 = s * CHUNK;
     if (k0 >= len) return;                    // inactive chunk: the merge only visits ceil(len/CHUNK) partials
     const int k1 = min(len, k0 + CHUNK);
     const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
-    const float* kb = a.kcache + head_off;
-    const float* vb = a.vcache + head_off;
+    const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
+    const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
 
     // ---- all loads first: K rows, then V rows (K returns first, V lands while the scores are reduced)
     f32x4 kreg[STEPS][NV], vreg[STEPS][NV];
     bool valid[STEPS];
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
-        const int kk = k0 + 32 * i + 8 * wid + g;
+        const int kk = k0 + KPS * i + KPW * wid + g;
         valid[i] = kk < k1;
         const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)(valid[i] ? kk : k0) * D);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) kreg[i][j] = kr[j * 8 + p];
+        for (int j = 0; j < NV; ++j) kreg[i][j] = kr[j * LPK + p];
     }
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
-        const int kk = k0 + 32 * i + 8 * wid + g;
+        const int kk = k0 + KPS * i + KPW * wid + g;
         const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)(valid[i] ? kk : k0) * D);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) vreg[i][j] = vr[j * 8 + p];
+        for (int j = 0; j < NV; ++j) vreg[i][j] = vr[j * LPK + p];
     }
-    f32x4 qv[NV];
-    const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (long long)b * a.hidden + h * D);
+    // this lane's query elements: dims (j*LPK + p)*EPL .. +EPL
+    float qv[NV][EPL];
+    const float* qp = a.q + (long long)b * a.hidden + h * D;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) qv[j] = qp[j * 8 + p];
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+        }
 
-    // ---- scores q.k / sqrt(D) (every lane of an 8-lane group ends up holding its key's score)
+    // ---- scores q.k / sqrt(D) (every lane of a key's lane group ends up holding its score)
     float sc[STEPS];
     float mloc = -INFINITY;
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) acc = dot4(qv[j], kreg[i][j], acc);
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
+        for (int j = 0; j < NV; ++j) {
+            float kf[EPL];
+            kv_unpack<KT>(kreg[i][j], kf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
+        }
+#pragma unroll
+        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
         sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
         mloc = fmaxf(mloc, sc[i]);
     }
@@ -109,32 +142,33 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_f32_kernel(AttnDecArgs a) {
     const float l = block_sum(lloc, red);
 
     // ---- o = sum_k p_k V_k
-    f32x4 o[NV];
+    float o[NV][EPL];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) o[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[j][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < STEPS; ++i)
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            o[j].x = fmaf(pw[i], vreg[i][j].x, o[j].x);
-            o[j].y = fmaf(pw[i], vreg[i][j].y, o[j].y);
-            o[j].z = fmaf(pw[i], vreg[i][j].z, o[j].z);
-            o[j].w = fmaf(pw[i], vreg[i][j].w, o[j].w);
-        }
-    // sum over the 8 key groups of the wave (lanes with equal p), then over the 4 waves
+            float vf[EPL];
+            kv_unpack<KT>(vreg[i][j], vf);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-#pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            o[j].x += __shfl_xor(o[j].x, off, 64);
-            o[j].y += __shfl_xor(o[j].y, off, 64);
-            o[j].z += __shfl_xor(o[j].z, off, 64);
-            o[j].w += __shfl_xor(o[j].w, off, 64);
+            for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
         }
-    }
+    // sum over the key groups of the wave (lanes with equal p), then over the 4 waves
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+            for (int off = LPK; off < 64; off <<= 1) o[j][e] += __shfl_xor(o[j][e], off, 64);
+        }
     if (g == 0) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) reinterpret_cast<f32x4*>(ored + wid * D)[j * 8 + p] = o[j];
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) ored[wid * D + (j * LPK + p) * EPL + e] = o[j][e];
     }
     __syncthreads();
     float* pout = a.part + (((long long)b * a.H + h) * a.S + s) * (D + 2);
@@ -147,9 +181,9 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_f32_kernel(AttnDecArgs a) {
 // partials: round 1 fetches every {m_s, l_s} at once (one per thread) and turns them into the merge
 // weights w_s = exp(m_s - M) in LDS; round 2 has thread (c, half) accumulate column c over the
 // partials of its half with unrolled, independent loads.
-template <int D, int STEPS>
-__global__ __launch_bounds__(ER_WG) void attn_combine_f32_kernel(AttnDecArgs a) {
-    constexpr int CHUNK = 32 * STEPS;
+template <int D>
+__global__ __launch_bounds__(ER_WG) void attn_combine_kernel(AttnDecArgs a) {
+    const int CHUNK = a.chunk;
     constexpr int W = D + 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [S] merge weights + [128] half sums + [8]
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -189,24 +223,30 @@ __global__ __launch_bounds__(ER_WG) void attn_combine_f32_kernel(AttnDecArgs a) 
     if (half == 0 && c < D) a.out[(long long)b * a.hidden + h * D + c] = (o + half1[c]) / l;
 }
 
-constexpr int ATTN_STEPS_DEFAULT = 4;          // 128 keys per workgroup
-inline int attn_num_chunks(int l_cap, int steps) { return (l_cap + 32 * steps - 1) / (32 * steps); }
+constexpr int ATTN_STEPS_DEFAULT = 4;          // fp32 KV: 128 keys per workgroup
+inline int attn_chunk(int steps, bool kv_half) { return (kv_half ? 64 : 32) * steps; }
+inline int attn_num_chunks(int l_cap, int chunk) { return (l_cap + chunk - 1) / chunk; }
 
+// `steps` is the fp32 step count (chunk = 32*steps keys); fp16 KV uses half as many steps for the same chunk.
 template <int D>
-inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, int B, hipStream_t st) {
+inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv_half, int B, hipStream_t st) {
     const dim3 grid(a.S, a.H, B), blk(ER_WG);
-    if (steps == 2) hipLaunchKernelGGL((attn_decode_f32_kernel<D, 2>), grid, blk, 0, st, a);
-    else if (steps == 8) hipLaunchKernelGGL((attn_decode_f32_kernel<D, 8>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((attn_decode_f32_kernel<D, 4>), grid, blk, 0, st, a);
+    if (!kv_half) {
+        if (steps == 2) hipLaunchKernelGGL((attn_decode_kernel<float, D, 2>), grid, blk, 0, st, a);
+        else if (steps == 8) hipLaunchKernelGGL((attn_decode_kernel<float, D, 8>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, D, 4>), grid, blk, 0, st, a);
+    } else {
+        if (steps == 2) hipLaunchKernelGGL((attn_decode_kernel<_Float16, D, 1>), grid, blk, 0, st, a);
+        else if (steps == 8) hipLaunchKernelGGL((attn_decode_kernel<_Float16, D, 4>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((attn_decode_kernel<_Float16, D, 2>), grid, blk, 0, st, a);
+    }
     return hipGetLastError();
 }
 template <int D>
-inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int steps, int B, hipStream_t st) {
+inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int B, hipStream_t st) {
     const dim3 grid(a.H, B), blk(ER_WG);
     const size_t lds = (size_t)(a.S + 128 + 8) * sizeof(float);
-    if (steps == 2) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 2>), grid, blk, lds, st, a);
-    else if (steps == 8) hipLaunchKernelGGL((attn_combine_f32_kernel<D, 8>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((attn_combine_f32_kernel<D, 4>), grid, blk, lds, st, a);
+    hipLaunchKernelGGL((attn_combine_kernel<D>), grid, blk, lds, st, a);
     return hipGetLastError();
 }
 

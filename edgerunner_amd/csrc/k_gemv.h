@@ -1,4 +1,5 @@
-// Weight-streaming GEMV for the decode step (batch 1..4 rows per pass), fp32.
+// Weight-streaming GEMV for the decode step (batch 1..4 rows per pass; 16 per pass in the batched
+// variant below); weights fp32 (exact mode) or fp16 (fast mode), fp32 accumulate.
 //
 // Replaces the per-token nn.Linear calls of the reference decoder
 // (core/transformer/modeling_opt.py:185,189-190 q/k/v, :232 out_proj, :281 fc1,
@@ -42,8 +43,9 @@ struct GemvArgs {
     float* out;            // [NB][N]
     const float* resid;    // EPI_RESID: [NB][N]
     float* q;              // EPI_QKV: [NB][hidden]
-    float* kcache;         //          [B][H][Lcap][D] (this layer)
-    float* vcache;
+    void* kcache;          //          [B][H][Lcap][D] (this layer), fp32 or fp16
+    void* vcache;
+    int kv_half;           //          1: the cache holds _Float16
     int hidden, head_dim, l_cap;
     long long kv_bstride;  // H*Lcap*D
 };
@@ -99,16 +101,20 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, f
             a.q[(long long)b * a.hidden + c] = v;
         } else {
             const int h = c / a.head_dim, d = c - h * a.head_dim;
-            float* cache = (which == 1) ? a.kcache : a.vcache;
-            cache[(long long)b * a.kv_bstride + ((long long)h * a.l_cap + e.pos) * a.head_dim + d] = v;
+            void* cache = (which == 1) ? a.kcache : a.vcache;
+            const long long idx = (long long)b * a.kv_bstride + ((long long)h * a.l_cap + e.pos) * a.head_dim + d;
+            if (a.kv_half) reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)v;     // round-to-nearest-even
+            else reinterpret_cast<float*>(cache)[idx] = v;
         }
     }
 }
 
-// K = KS * J * 256.  Dynamic LDS: NB*K floats (input) + 64 floats scratch.
-template <int J, int KS, int NB, int RW, int PRO, int EPI>
-__global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
-    constexpr int K = KS * J * 256;
+// K = KS * 1536 (a wave reduces one 1536-slice = J 16-byte loads per lane, J = 6 for fp32 weights,
+// 3 for fp16).  Dynamic LDS: NB*K floats (input) + 64 floats scratch.
+template <typename WT, int KS, int NB, int RW, int PRO, int EPI>
+__global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
+    constexpr int EPL = WTraits<WT>::EPL, XV = EPL / 4, SL = 1536, J = SL / (64 * EPL);
+    constexpr int K = KS * SL;
     constexpr int PT = K / ER_WG;  // elements per thread in the prologue
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;              // [NB][K]
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         const int row = min(row0 + r, a.N - 1);            // clamp: out-of-range rows are loaded but never stored
-        const f32x4* wr = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.W) + (long long)row * K + slice * (J * 256));
+        const f32x4* wr = reinterpret_cast<const f32x4*>(reinterpret_cast<const WT*>(a.W) + (long long)row * K + slice * SL);
 #pragma unroll
         for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
     }
@@ -180,12 +186,14 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
     __syncthreads();
 
     // ---------------- main: dot the (already in flight) weight rows with the input
-    f32x4 xr[NB][J];
+    f32x4 xr[NB][J * XV];      // the EPL inputs matching load j are float4 #(j*64+lane)*XV .. +XV of the slice
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            xr[b][j] = reinterpret_cast<const f32x4*>(xs + b * K + slice * (J * 256))[j * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < XV; ++u)
+                xr[b][j * XV + u] = reinterpret_cast<const f32x4*>(xs + b * K + slice * SL)[(j * 64 + lane) * XV + u];
 
     float acc[RW][NB];
 #pragma unroll
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
         for (int b = 0; b < NB; ++b) {
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < J; ++j) s = dot4(w[r][j], xr[b][j], s);
+            for (int j = 0; j < J; ++j) s = dot_w<WT>(w[r][j], &xr[b][j * XV], s);
             acc[r][b] = wave_sum(s);
         }
 
@@ -225,14 +233,14 @@ __global__ __launch_bounds__(ER_WG) void gemv_f32_kernel(GemvArgs a) {
     }
 }
 
-template <int J, int KS, int NB, int RW, int PRO, int EPI>
+template <typename WT, int KS, int NB, int RW, int PRO, int EPI>
 inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t st) {
     static_assert(KS == 1 || KS == ER_NWAVES, "K is reduced by one wave or by all four");
-    constexpr int K = KS * J * 256;
+    constexpr int K = KS * 1536;
     const int rows_per_block = (KS == 1) ? ER_NWAVES * RW : RW;
     const int grid = (a.N + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)(NB * K + 64) * sizeof(float);
-    hipLaunchKernelGGL((gemv_f32_kernel<J, KS, NB, RW, PRO, EPI>), dim3(grid), dim3(ER_WG), lds, st, a);
+    hipLaunchKernelGGL((gemv_kernel<WT, KS, NB, RW, PRO, EPI>), dim3(grid), dim3(ER_WG), lds, st, a);
     return hipGetLastError();
 }
 
@@ -387,7 +395,7 @@ inline hipError_t launch_gemv_batched(const GemvArgs& a, int nb_valid, hipStream
     return hipGetLastError();
 }
 
-// One workgroup per batch row: the LayerNorm / embedding prologue of gemv_f32_kernel as its own kernel
+// One workgroup per batch row: the LayerNorm / embedding prologue of gemv_kernel as its own kernel
 // (identical thread->element mapping and reduction order), writing the GEMV input / residual row.
 template <int PRO>
 __global__ __launch_bounds__(ER_WG) void prep_rows_kernel(GemvArgs a) {

@@ -137,6 +137,27 @@ __global__ __launch_bounds__(ER_WG) void gather_rows_kernel(const float* table, 
     for (int c = threadIdx.x; c < C; c += ER_WG) dst[c] = src[c];
 }
 
+// Fast mode prefill: move the K/V columns of the fused projection output qkv[M][3*hidden] into the fp16
+// cache [B][H][Lcap][D] (what modeling_opt.py:189-192 stores, in the reference's GPU dtype) and round the
+// scratch copy through fp16 in place, so the prefix attention sees exactly the values later steps will read.
+__global__ __launch_bounds__(ER_WG) void kv_scatter_half_kernel(float* qkv, _Float16* kcache, _Float16* vcache, int M,
+                                                                int S, int hidden, int head_dim, int l_cap,
+                                                                long long kv_bstride) {
+    const long long total = (long long)M * 2 * hidden;
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
+        const long long m = i / (2 * hidden);
+        const int c2 = (int)(i - m * 2 * hidden);
+        const int which = c2 / hidden, c = c2 - which * hidden;       // 0 = K, 1 = V
+        const int b = (int)(m / S), s = (int)(m - (long long)b * S);
+        const int h = c / head_dim, d = c - h * head_dim;
+        float* src = qkv + m * 3 * hidden + hidden + c2;
+        const _Float16 hv = (_Float16)*src;
+        *src = (float)hv;
+        _Float16* cache = which == 0 ? kcache : vcache;
+        cache[(long long)b * kv_bstride + ((long long)h * l_cap + s) * head_dim + d] = hv;
+    }
+}
+
 inline int ew_grid(long long total) {
     long long g = (total + ER_WG - 1) / ER_WG;
     if (g > 2048) g = 2048;

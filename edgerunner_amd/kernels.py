@@ -28,12 +28,13 @@ def gemv(w, x, bias=None, ln_w=None, ln_b=None, resid=None, relu=False, eps=1e-5
 
 
 def attn_decode(q, k_cache, v_cache, lens, steps=4):
-    """q [B,H*D]; caches [B,H,Lcap,D]; lens: list[int] -> out [B,H*D]."""
+    """q [B,H*D] fp32; caches [B,H,Lcap,D] fp32 or fp16; lens: list[int] -> out [B,H*D]."""
     lib = native.load_library()
     B, H, Lcap, D = k_cache.shape
     out = torch.empty((B, H * D), dtype=torch.float32, device=q.device)
     native.check(lib.er_k_attn_decode(native.ptr(q), native.ptr(k_cache), native.ptr(v_cache), native.i32_array(lens),
-                                      native.ptr(out), B, H, D, Lcap, steps, _st()), "er_k_attn_decode")
+                                      native.ptr(out), B, H, D, Lcap, steps, int(k_cache.dtype == torch.float16), _st()),
+                 "er_k_attn_decode")
     return out
 
 

@@ -38,8 +38,14 @@ class _DecoderModel:
 
 
 class LMM:
-    def __init__(self, opt, device="cuda:0"):
+    def __init__(self, opt, device="cuda:0", precision: str = "fp32"):
+        """precision: 'fp32' = exact mode (fp32 weights + KV; greedy ids bit-exact vs the CPU path) or
+        'fp16' = fast mode (decoder matrices and KV cache stored in fp16 like the reference's
+        ``model.half()`` GPU path, fp32 accumulate)."""
         self.opt = opt
+        if precision not in ("fp32", "fp16"):
+            raise ValueError(precision)
+        self.precision = precision
         if opt.cond_mode == "image":
             raise NotImplementedError("cond_mode='image' (CLIP conditioner) is outside the ArAE decode path")
         if opt.cond_mode == "point" and opt.point_encoder_mode != "embed":
@@ -47,7 +53,8 @@ class LMM:
         self.dims = dims_from_options(opt)
         self.vocab_size = self.dims.vocab_size
         self.device = torch.device(device)
-        self.mesh_decoder = NativeShapeOPT(self.dims, opt, self.device)
+        dt = torch.float32 if precision == "fp32" else torch.float16
+        self.mesh_decoder = NativeShapeOPT(self.dims, opt, self.device, weight_dtype=dt, kv_dtype=dt)
         self.mesh_decoder.model = _DecoderModel(self.mesh_decoder)
         self.training = False
         self._dtype_requested = torch.float32
@@ -57,8 +64,8 @@ class LMM:
         return self.mesh_decoder.load_state_dict(sd, strict=strict)
 
     def half(self):
-        # The reference casts to fp16 here (infer.py:56).  This round builds the exact fp32
-        # streaming mode only (bit-exact greedy parity with the CPU path); the request is recorded.
+        # The reference casts to fp16 here (infer.py:56).  Storage precision is fixed when the context is
+        # created - LMM(..., precision='fp16') is the counterpart; the request is only recorded.
         self._dtype_requested = torch.float16
         return self
 

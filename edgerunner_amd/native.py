@@ -81,7 +81,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     i32p = C.POINTER(C.c_int32)
     lib.er_meto_decode.argtypes = [i32p, ci, ci, C.POINTER(C.c_float), i32p, i32p, i32p, i32p, i32p]
     lib.er_k_gemv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
-    lib.er_k_attn_decode.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), vp, ci, ci, ci, ci, ci, vp]
+    lib.er_k_attn_decode.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), vp, ci, ci, ci, ci, ci, ci, vp]
     lib.er_k_gemm.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp]
     lib.er_k_layernorm.argtypes = [vp, vp, vp, vp, ci, ci, cf, vp]
     lib.er_k_softmax.argtypes = [vp, ci, ci, ci, ci, vp]

@@ -165,8 +165,9 @@ int er_k_gemv(const float* w_dev, const float* bias_dev, const float* x_dev, con
               int batch, int n, int k, int relu, float eps, void* stream);
 /* softmax(q K^T / sqrt(D)) V for one new token over a [B,H,Lcap,D] cache holding len[b] keys;
  * steps in {2,4,8}: one workgroup per chunk of 32*steps keys */
-int er_k_attn_decode(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* len_host,
-                     float* out_dev, int batch, int heads, int head_dim, int l_cap, int steps, void* stream);
+int er_k_attn_decode(const float* q_dev, const void* k_dev, const void* v_dev, const int32_t* len_host,
+                     float* out_dev, int batch, int heads, int head_dim, int l_cap, int steps, int kv_half,
+                     void* stream);
 /* C[M,N] = A[M,K] op(B) (+bias)(relu)(+resid); b_is_kn=0: B is [N,K] (Linear weight), 1: B is [K,N] */
 int er_k_gemm(const float* a_dev, const float* b_dev, const float* bias_dev, const float* resid_dev,
               float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int b_is_kn, int relu,

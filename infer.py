@@ -49,7 +49,9 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: this path has no CPU fallback")
     device = torch.device("cuda", local)
-    model = LMM(opt, device)
+    # the reference runs fp16 on GPU (infer.py:56,105): 'fp16' = that storage precision, fp32 accumulate;
+    # EDGERUNNER_PRECISION=fp32 selects the exact mode (greedy ids bit-exact vs the CPU path)
+    model = LMM(opt, device, precision=os.environ.get("EDGERUNNER_PRECISION", "fp16"))
     if opt.resume is not None:
         if opt.resume.endswith("safetensors"):
             from safetensors.torch import load_file

@@ -140,7 +140,18 @@ def encode_cond(sd: StateDict, opt, conds, num_faces):
 Past = Optional[List[Tuple[torch.Tensor, torch.Tensor]]]
 
 
-def decoder_forward(sd: StateDict, opt, input_ids=None, inputs_embeds=None, past: Past = None):
+STREAMED_SUFFIXES = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                     "self_attn.out_proj.weight", "fc1.weight", "fc2.weight", "lm_head.weight")
+
+
+def round_streamed_weights(sd: StateDict, dtype=torch.float16) -> StateDict:
+    """Test helper for the fp16 'fast' storage mode: the decoder matrices that are streamed per token,
+    rounded through `dtype` (what the reference's ``model.half()`` does to them, infer.py:56) and kept as
+    fp32 tensors, so the restated fp32 arithmetic below runs on exactly the values the device streams."""
+    return {k: (v.to(dtype).float() if k.endswith(STREAMED_SUFFIXES) else v) for k, v in sd.items()}
+
+
+def decoder_forward(sd: StateDict, opt, input_ids=None, inputs_embeds=None, past: Past = None, kv_round=None):
     """ShapeOPT.forward with use_cache=True (core/transformer/modeling_opt.py:464-517
     -> ShapeOPTDecoder.forward :321-426 -> OPTDecoderLayer.forward :253-298 ->
     OptFlashAttention2.forward :172-237).  Returns (logits [B,S,V], new past)."""
@@ -161,6 +172,8 @@ def decoder_forward(sd: StateDict, opt, input_ids=None, inputs_embeds=None, past
         q = _lin(sd, f"{L}.self_attn.q_proj", h)                              # :185
         k = _lin(sd, f"{L}.self_attn.k_proj", h).view(B, -1, H, D).transpose(1, 2).contiguous()  # :169-170,189
         v = _lin(sd, f"{L}.self_attn.v_proj", h).view(B, -1, H, D).transpose(1, 2).contiguous()
+        if kv_round is not None:   # fast-mode emulation: K/V are stored in the cache dtype (fp16 under infer.py:56,105)
+            k, v = k.to(kv_round).float(), v.to(kv_round).float()
         if past is not None:                                                  # :191-192
             k = torch.cat([past[i][0], k], dim=2)
             v = torch.cat([past[i][1], v], dim=2)
@@ -259,11 +272,11 @@ def sample_from_uniform(filtered_scores_row, u: float) -> int:
 
 
 # ----------------------------------------------------------------------------- generation loop
-def make_forward(sd: StateDict, opt) -> Callable:
+def make_forward(sd: StateDict, opt, kv_round=None) -> Callable:
     """fwd(input_ids=None, inputs_embeds=None, past=None) -> (logits, past) over this
     restatement; ``make_golden.py`` substitutes the reference's own ShapeOPT here."""
     def fwd(input_ids=None, inputs_embeds=None, past=None):
-        return decoder_forward(sd, opt, input_ids=input_ids, inputs_embeds=inputs_embeds, past=past)
+        return decoder_forward(sd, opt, input_ids=input_ids, inputs_embeds=inputs_embeds, past=past, kv_round=kv_round)
     return fwd
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate decode throughput at batch B (independent clouds, greedy, EOS suppressed) on one GPU.
-BASELINE configs[2]/[3] shapes: B=32, T=4*num_face.  Usage: bench_batch.py B T [num_face]"""
+BASELINE configs[2]/[3] shapes: B=32, T=4*num_face.  Usage: bench_batch.py B[,B..] T [num_face] [fp32|fp16]"""
 import dataclasses
 import json
 import os
@@ -20,8 +20,10 @@ def main():
     Bs = [int(x) for x in sys.argv[1].split(",")]
     T = int(sys.argv[2])
     nf = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+    precision = sys.argv[4] if len(sys.argv) > 4 else "fp32"
+    esz = 4 if precision == "fp32" else 2
     opt = dataclasses.replace(config_defaults["ArAE"], num_layers=24, generate_mode="greedy")
-    lmm = LMM(opt, "cuda:0")
+    lmm = LMM(opt, "cuda:0", precision=precision)
     lmm.mesh_decoder.load_state_iter(W.iter_state_dict(opt, 0, "perturbed"), strict=True)
     for B in Bs:
         pcs = torch.cat([W.synthetic_point_cloud(i, 4096) for i in range(B)]).to("cuda:0")
@@ -31,8 +33,8 @@ def main():
         wall = time.perf_counter() - t0
         ms = lmm.mesh_decoder.last_decode_ms
         mean_L = 2050 + (T - 1) / 2
-        bytes_step = 680_752_128 * 4 + B * 73_728 * (mean_L + 1) * 4
-        print(json.dumps({"B": B, "T": T, "decode_ms": round(ms, 1), "ms_per_step": round(ms / T, 3),
+        bytes_step = 680_752_128 * esz + B * 73_728 * (mean_L + 1) * esz
+        print(json.dumps({"precision": precision, "B": B, "T": T, "decode_ms": round(ms, 1), "ms_per_step": round(ms / T, 3),
                           "aggregate_tok_s": round(B * T / ms * 1e3, 1), "end_to_end_tok_s": round(B * T / wall, 1),
                           "algorithmic_GBps": round(bytes_step / (ms / T * 1e-3) / 1e9, 1),
                           }), flush=True)

@@ -118,6 +118,22 @@ def test_attn_decode(D, lens, steps):
         close(out[b], ref, 2e-6, 1e-5, f"attn row {b} len {n}")
 
 
+@pytest.mark.parametrize("D,lens,steps", [(96, [2051, 700], 4), (96, [1, 65, 6049], 4), (64, [300], 2), (96, [129], 8)])
+def test_attn_decode_fp16_cache(D, lens, steps):
+    from edgerunner_amd import kernels as K
+    B, H = len(lens), 16
+    Lcap = (max(lens) + 63) // 64 * 64
+    q = rnd(B, H * D, seed=23)
+    kc, vc = rnd(B, H, Lcap, D, seed=24).half(), rnd(B, H, Lcap, D, seed=25).half()
+    for b, n in enumerate(lens):
+        kc[b, :, n:] = float("nan")
+        vc[b, :, n:] = float("nan")
+    out = K.attn_decode(q, kc, vc, lens, steps)
+    for b, n in enumerate(lens):
+        w = torch.softmax(q[b].view(H, 1, D).double() @ kc[b, :, :n].double().transpose(1, 2) / math.sqrt(D), dim=-1)
+        close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"fp16-KV attn row {b} len {n}")
+
+
 # ------------------------------------------------------------------ MFMA GEMM (prefill / encoder)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (2050, 1536, 1536), (2050, 6144, 1536), (300, 64, 1024),
                                    (2048, 1024, 64), (77, 200, 96)])

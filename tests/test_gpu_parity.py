@@ -19,14 +19,14 @@ LOGIT_TOL = 1e-3
 _CACHE = {}
 
 
-def make_lmm(num_layers=2, seed=0, style="perturbed", **kw):
+def make_lmm(num_layers=2, seed=0, style="perturbed", precision="fp32", **kw):
     from edgerunner_amd import weights as W
     from edgerunner_amd.models import LMM
     from edgerunner_amd.options import config_defaults
-    key = (num_layers, seed, style, tuple(sorted(kw.items())), os.environ.get("ER_NO_GRAPH", ""))
+    key = (num_layers, seed, style, precision, tuple(sorted(kw.items())), os.environ.get("ER_NO_GRAPH", ""))
     if key not in _CACHE:
         opt = dataclasses.replace(config_defaults["ArAE"], num_layers=num_layers, generate_mode="greedy", **kw)
-        m = LMM(opt, DEV)
+        m = LMM(opt, DEV, precision=precision)
         missing, unexpected = m.mesh_decoder.load_state_iter(W.iter_state_dict(opt, seed, style), strict=True)
         assert not missing and not unexpected
         _CACHE[key] = m
@@ -258,6 +258,42 @@ def test_sample_mode_deterministic_and_grammatical():
     for t in ids:
         assert t in st.allowed(last), "sampled token violates the grammar"
         last = t
+
+
+# ------------------------------------------------------------------ fast mode (fp16 storage, fp32 accumulate)
+def test_fast_mode_vs_storage_rounding_emulation(gold_small):
+    """fp16 weights + fp16 KV: must match the oracle run on fp16-ROUNDED weights with K/V rounded to fp16 at the
+    cache write and fp32 arithmetic everywhere (i.e. only storage is reduced) - ids exact, logits <= 1e-3; the
+    distance to the fp32 goldens is reported, not asserted."""
+    import arae_oracle as O
+    from edgerunner_amd import weights as W
+    lmm = make_lmm(precision="fp16")
+    sd = O.round_streamed_weights(W.make_state_dict(lmm.opt, 0, "perturbed"), torch.float16)
+    pc = W.synthetic_point_cloud(0, 4096)
+    rec = {}
+    want = O.lmm_generate_ids(sd, lmm.opt, pc, 1000, max_new_tokens=64, min_new_tokens=64,
+                              fwd=O.make_forward(sd, lmm.opt, kv_round=torch.float16),
+                              record_logits=lambda t, s: rec.__setitem__(t, s.numpy()[0].copy())).numpy()[0]
+    _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
+    assert_ids(toks[0], want, "fast mode vs fp16-storage emulation")
+    got = teacher_forced_logits(lmm, cloud(0), 1000, want, set(range(64)))
+    err = max(np.abs(got[t] - rec[t]).max() for t in range(64))
+    gold = gold_small["logits_min96"][:, 0]
+    same_prefix = first_diff(want, gold_small["ids_min96"][0][:64])
+    n_cmp = 64 if same_prefix is None else same_prefix + 1
+    drift = max(np.abs(got[t] - gold[t]).max() for t in range(n_cmp))
+    print(f"fast mode: max|dlogit| vs emulation {err:.3e}; vs fp32 reference (first {n_cmp} steps) {drift:.3e}; "
+          f"ids equal to the fp32 run for {'all 64' if same_prefix is None else same_prefix} steps")
+    assert err < LOGIT_TOL
+
+
+def test_fast_mode_batched_rows_bit_identical():
+    lmm = make_lmm(precision="fp16")
+    batch = torch.cat([cloud(i % 2) for i in range(6)])
+    _, toks = lmm.generate(batch, 1000, tokenizer=object(), max_new_tokens=48, min_new_tokens=48)
+    _, one = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=48, min_new_tokens=48)
+    for r in (0, 2, 4):
+        assert_ids(toks[r], one[0], f"fp16 row {r} of a 6-row batch vs its single run")
 
 
 # ------------------------------------------------------------------ BASELINE configs[1]: full size, T = 4000
