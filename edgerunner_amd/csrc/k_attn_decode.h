@@ -30,7 +30,7 @@ struct AttnDecArgs {
     float* part;           // [B][H][S][D+2] = {m, l, o[0..D)}
     float* out;            // combine: [B][hidden]
     int H, l_cap, S, hidden;   // S = number of chunks the grid covers = ceil(l_cap / chunk)
-    int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS)
+    int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS with half the steps)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
 };
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(ER_WG) void attn_combine_kernel(AttnDecArgs a) {
 }
 
 constexpr int ATTN_STEPS_DEFAULT = 4;          // fp32 KV: 128 keys per workgroup
-inline int attn_chunk(int steps, bool kv_half) { return (kv_half ? 64 : 32) * steps; }
+inline int attn_chunk(int steps, bool /*kv_half*/) { return 32 * steps; }   // fp16 KV: 64 keys/step x steps/2
 inline int attn_num_chunks(int l_cap, int chunk) { return (l_cap + chunk - 1) / chunk; }
 
 // `steps` is the fp32 step count (chunk = 32*steps keys); fp16 KV uses half as many steps for the same chunk.
