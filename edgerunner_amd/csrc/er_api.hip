@@ -586,7 +586,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->hbuf;
-                return gemv_batched_groups<WT, 1, 2, EPI_QKV>(a, B, H, st);
+                return gemv_batched_groups<WT, 1, 3, EPI_QKV>(a, B, H, st);   // 4608 rows = 192 workgroups x 24: one round
             }
             if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
             return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st);
@@ -607,7 +607,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->h1buf;
-                return gemv_batched_groups<WT, 1, 2, EPI_RELU>(a, B, H, st);
+                return gemv_batched_groups<WT, 1, 3, EPI_RELU>(a, B, H, st);   // 6144 rows = 256 workgroups x 24
             }
             return gemv_rw<WT, 1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
         }

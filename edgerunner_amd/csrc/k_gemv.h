@@ -315,40 +315,39 @@ __global__ __launch_bounds__(GB_THREADS) void gemv_batched_kernel(GemvArgs a, in
 #pragma unroll
     for (int r = 0; r < RW; ++r) pre[r] = gemv_epi_prefetch<EPI>(a, row0 + r, min(b_own, nb_valid - 1));
 
+    // input staging: each thread moves FILL float4 of the [NB][1536] slice image; the loads of slice ph+1 are
+    // issued before slice ph is consumed and land in registers while it is being multiplied
+    constexpr int PER_ROW = SL / 4, FILL = NB * PER_ROW / GB_THREADS;   // 12 at NB = 16
+    static_assert(NB * PER_ROW % GB_THREADS == 0, "fill loop shape");
+    f32x4 xf[FILL];
+    auto issue_fill = [&](int ph) {
+#pragma unroll
+        for (int u = 0; u < FILL; ++u) {
+            const int i = tid + u * GB_THREADS;
+            const int b = i / PER_ROW, c = i - b * PER_ROW;
+            // unconditional load from a clamped row (a per-element branch would serialise the loads);
+            // rows >= nb_valid replicate the last valid row, their accumulators are never stored
+            xf[u] = reinterpret_cast<const f32x4*>(a.xin + (long long)min(b, nb_valid - 1) * K + ph * SL)[c];
+        }
+    };
+    issue_fill(0);
+
     float total[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) total[r] = 0.f;
 #pragma unroll 1
     for (int ph = 0; ph < PH; ++ph) {      // a real loop: unrolling the phases lets the scheduler pile up 4x the live values
-        if (ph > 0) __syncthreads();
-        // keep each slice's staging loads inside its own phase (hoisting all PH fills to the top spills)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if (ph > 0) __syncthreads();       // readers of the previous slice image are done
+#pragma unroll
+        for (int u = 0; u < FILL; ++u) reinterpret_cast<f32x4*>(xs)[tid + u * GB_THREADS] = xf[u];
+        __syncthreads();
         if (ph + 1 < PH) {
 #pragma unroll
             for (int r = 0; r < RW; ++r)
 #pragma unroll
                 for (int j = 0; j < J; ++j) wn[r][j] = __builtin_nontemporal_load(wrow[r] + ((ph + 1) * J + j) * 64 + lane);
+            issue_fill(ph + 1);
         }
-        {   // stage the nb_valid input rows of this slice: independent loads issued in batches of 8, then
-            // written (rows >= nb_valid stay uninitialised: their accumulators are never stored)
-            constexpr int PER_ROW = SL / 4, FILL = NB * PER_ROW / GB_THREADS;   // float4 per thread (12 at NB = 16)
-            static_assert(NB * PER_ROW % GB_THREADS == 0 && FILL % 4 == 0, "fill loop shape");
-#pragma unroll
-            for (int i0 = 0; i0 < FILL; i0 += 4) {
-                f32x4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = tid + (i0 + u) * GB_THREADS;
-                    const int b = i / PER_ROW, c = i - b * PER_ROW;
-                    // unconditional load from a clamped row: a per-element branch would serialise the loads
-                    v[u] = reinterpret_cast<const f32x4*>(a.xin + (long long)min(b, nb_valid - 1) * K + ph * SL)[c];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4*>(xs)[tid + (i0 + u) * GB_THREADS] = v[u];
-            }
-        }
-        __syncthreads();
         AccRow<NB> acc[RW];
 #pragma unroll
         for (int r = 0; r < RW; ++r)
