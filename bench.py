@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=120, help="decode steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--precision", choices=("fp32", "fp16"), default="fp32",
+                    help="fp32 = exact mode (the mode whose ids are bit-exact vs the CPU path; default); fp16 = fast mode")
+    ap.add_argument("--no-fast-extra", action="store_true", help="skip the additional fp16 fast-mode measurement")
     args = ap.parse_args()
 
     from edgerunner_amd import dist as D
@@ -141,7 +144,8 @@ def main():
     opt = dataclasses.replace(config_defaults["ArAE"], num_layers=args.layers, generate_mode="greedy")
 
     t0 = time.time()
-    lmm = LMM(opt, dev)
+    lmm = LMM(opt, dev, precision=args.precision)
+    esz = 4 if args.precision == "fp32" else 2
     keep_sd = rank == 0 and world == 1 and args.cpu_steps > 0
     sd = {}
     def items():
@@ -187,7 +191,7 @@ def main():
     dom = max(per_token_us, key=per_token_us.get)
     ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
     mean_L = 2050 + (T - 1) / 2.0
-    bytes_per_token = W_ELEMS * 4 + KV_ELEMS_PER_POS * (mean_L + 1) * 4
+    bytes_per_token = W_ELEMS * esz + KV_ELEMS_PER_POS * (mean_L + 1) * esz
     traffic = pmc_traffic(dom)
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -205,7 +209,7 @@ def main():
         "metric": "mesh tokens/sec (whole node), ArAE greedy test_num_face=1000",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16 storage / f32 accumulate", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: ArAE random-init (seeded synthetic checkpoint), batch 1 per GPU, greedy, "
                                f"test_num_face={args.num_face}, {T} new tokens (EOS suppressed until T), "
                                f"{args.points}-point synthetic cloud; step = encode_cond + 2050-token prefill + {T}-token decode"
@@ -215,6 +219,23 @@ def main():
         "decode_only_tokens_per_s": round(decode_only, 2),
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and args.precision == "fp32" and not args.no_fast_extra:
+        # secondary figure (not `value`): the same workload in the fp16-storage fast mode, the reference's GPU dtype
+        del lmm
+        torch.cuda.empty_cache()
+        fast = LMM(opt, dev, precision="fp16")
+        fast.mesh_decoder.load_state_iter(W.iter_state_dict(opt, 0, "perturbed"), strict=True)
+        pc = W.synthetic_point_cloud(0, args.points).to(dev)
+        for _ in range(2):
+            fast.generate(pc, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+        fb = W_ELEMS * 2 + KV_ELEMS_PER_POS * (mean_L + 1) * 2
+        ftok = T / (fast.mesh_decoder.last_decode_ms / 1e3)
+        out["fast_mode_fp16"] = {"decode_only_tokens_per_s": round(ftok, 2), "bytes_per_token": fb,
+                                 "hbm_frac": round(ftok * fb / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "fp16 weights + fp16 KV, fp32 accumulate; parity = ids exact / logits 5e-6 vs the "
+                                         "oracle on fp16-rounded storage (tests/test_gpu_parity.py), ~1e-3 vs fp32"}
+        del fast
+        log("fast-mode pass done")
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_steps, args.points)
         out["gpu_over_cpu"] = round(out["decode_only_tokens_per_s"] / out["cpu_baseline"]["value"], 1)

@@ -146,9 +146,10 @@ __global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
         pre[0][0] = gemv_epi_prefetch<EPI>(a, row0 + t / NB, t % NB);
     }
 
-    // ---------------- prologue: build the input vector(s) in LDS
+    // ---------------- prologue: build the input vector(s) in LDS (PRO_NONE reads them straight into the
+    // dot-product register layout below: no staging, no barrier)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NB && PRO != PRO_NONE; ++b) {
         float v[PT];
         if (PRO == PRO_EMBED) {
             const float* e = a.embd + (long long)a.tok[b] * K;
@@ -183,17 +184,19 @@ __global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
             for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * ER_WG] = v[i];
         }
     }
-    __syncthreads();
+    if (PRO != PRO_NONE) __syncthreads();
 
     // ---------------- main: dot the (already in flight) weight rows with the input
     f32x4 xr[NB][J * XV];      // the EPL inputs matching load j are float4 #(j*64+lane)*XV .. +XV of the slice
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+        const float* xsrc = (PRO == PRO_NONE) ? a.xin + (long long)b * K + slice * SL : xs + b * K + slice * SL;
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int u = 0; u < XV; ++u)
-                xr[b][j * XV + u] = reinterpret_cast<const f32x4*>(xs + b * K + slice * SL)[(j * 64 + lane) * XV + u];
+                xr[b][j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
+    }
 
     float acc[RW][NB];
 #pragma unroll
