@@ -296,6 +296,94 @@ def test_fast_mode_batched_rows_bit_identical():
         assert_ids(toks[r], one[0], f"fp16 row {r} of a 6-row batch vs its single run")
 
 
+# ------------------------------------------------------------------ error behaviour of the boundary
+def test_boundary_errors_are_loud():
+    from edgerunner_amd import native
+    from edgerunner_amd.models import LMM
+    from edgerunner_amd.options import config_defaults
+    lmm = make_lmm()
+    dec = lmm.mesh_decoder
+    cond = lmm.encode_cond(cloud(0, 256), [1000])["cond_embeds"]
+    emb = torch.cat((cond, dec.embd(torch.tensor([[1]]))), dim=1)
+    with pytest.raises(ValueError, match="empty list"):          # same error the patched HF processor raises (core/utils.py:129-134)
+        dec.generate(inputs_embeds=emb, max_new_tokens=4, prefix_allowed_tokens_fn=lambda b, ids: [])
+    with pytest.raises(native.NativeError, match="out of range"):
+        dec.embd(torch.tensor([[9999]]))
+    with pytest.raises(native.NativeError, match="position table"):
+        dec.reserve(1, 10 ** 6)
+    dec.prefill(emb, 8)
+    with pytest.raises(native.NativeError, match="out of range"):
+        dec.feed([518])
+    with pytest.raises(NotImplementedError):
+        dec.generate(inputs_embeds=emb, max_new_tokens=4, num_beams=4)
+    # a context without weights refuses to run instead of computing garbage
+    empty = LMM(dataclasses.replace(config_defaults["ArAE"], num_layers=1), DEV)
+    with pytest.raises(native.NativeError, match="never loaded"):
+        empty.encode_cond(cloud(0, 64), [1000])
+    with pytest.raises(native.NativeError, match="hidden_dim"):
+        LMM(dataclasses.replace(config_defaults["ArAE"], hidden_dim=1024, num_layers=1), DEV)
+
+
+def test_tiny_and_ragged_point_clouds():
+    import arae_oracle as O
+    from edgerunner_amd import weights as W
+    lmm = make_lmm()
+    sd = W.make_state_dict(lmm.opt, 0, "perturbed")
+    for n in (1, 15, 17, 129):
+        pc = W.synthetic_point_cloud(9, n)
+        ref = O.encode_cond(sd, lmm.opt, pc, torch.tensor([1000]))
+        got = lmm.encode_cond(pc.to(DEV), [1000])["cond_embeds"].cpu()
+        assert float((got - ref).abs().max()) < 2e-4, n
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] shard: 32 rows per GPU, T = 4000
+def test_config4_shard_B32_T4000_row0_bit_exact(gold_full):
+    """One GPU's share of BASELINE configs[3] (256 clouds over 8 GPUs = 32 per GPU, greedy, T = 4000) in the exact
+    mode: 32 different clouds in one batch; row 0 (cloud 0) must reproduce the reference CPU ids bit for bit
+    (batch rows are independent and bit-identical to single runs by construction), every row must obey the
+    grammar and stay EOS-free, and the aggregate rate is printed."""
+    from edgerunner_amd.grammar import GrammarState
+    from edgerunner_amd import native
+    lmm = make_lmm(num_layers=24)
+    want = gold_full["ids"][0]
+    T = len(want)
+    batch = torch.cat([cloud(i) for i in range(32)])
+    _, toks = lmm.generate(batch, 1000, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+    ms = lmm.mesh_decoder.last_decode_ms
+    print(f"B=32 x T={T}: decode {ms:.0f} ms -> {32 * T / ms * 1e3:.0f} tok/s aggregate")
+    assert_ids(toks[0], want, "row 0 of the 32-row shard vs the reference CPU run")
+    assert len({tuple(t[:64]) for t in toks}) > 1, "different clouds should not all give the same stream"
+    for r in (1, 7, 31):
+        st, last = GrammarState(native.ER_GRAMMAR_LR_ABSCO, 518), None
+        for t in toks[r].tolist():
+            assert t in st.allowed(last) and t != 2
+            last = t
+    lmm.mesh_decoder.reserve(1, 4096)     # release the 57 GB cache
+
+
+def test_sample_mode_batch_config3_like():
+    """configs[2] shape at reduced length: B = 32 sample mode (top-k 10): deterministic per seed, rows are
+    independent streams (row b depends on (seed, step, b) only), every row obeys the grammar."""
+    from edgerunner_amd.grammar import GrammarState
+    from edgerunner_amd import native
+    lmm = make_lmm()
+    lmm.opt.generate_mode = "sample"
+    try:
+        batch = torch.cat([cloud(0) for _ in range(32)])
+        a = lmm.generate_ids(batch, 4000, tokenizer=object(), max_new_tokens=200, min_new_tokens=200, seed=5)
+        b = lmm.generate_ids(batch, 4000, tokenizer=object(), max_new_tokens=200, min_new_tokens=200, seed=5)
+    finally:
+        lmm.opt.generate_mode = "greedy"
+    assert torch.equal(a, b)
+    rows = a.cpu().numpy()
+    assert len({tuple(r) for r in rows}) > 16, "same cloud, different Philox rows: streams must differ"
+    for r in rows[::5]:
+        st, last = GrammarState(native.ER_GRAMMAR_LR_ABSCO, 518), None
+        for t in r.tolist():
+            assert t in st.allowed(last)
+            last = t
+
+
 # ------------------------------------------------------------------ BASELINE configs[1]: full size, T = 4000
 def test_full_size_greedy_T4000_bit_exact(gold_full, manifest):
     """ArAE 24 layers, cloud 0 (4096 pts), greedy, test_num_face=1000, 4000 new tokens with EOS
