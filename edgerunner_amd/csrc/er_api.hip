@@ -20,6 +20,7 @@
 #include "k_head.h"
 #include "k_rowops.h"
 #include "meto_decode.h"
+#include "meto_encode.h"
 
 using namespace er;
 
@@ -1208,5 +1209,22 @@ extern "C" int er_meto_decode(const int32_t* tokens, int n, int bins, float* v, 
         return fail(ER_ERR_INVALID, "er_meto_decode: bad argument");
     const MetoCounts c = meto_decode_lr_absco(tokens, n, bins, v, f, t);
     *nv = c.vertices; *nf = c.faces; *nt = c.face_types;
+    return ER_OK;
+}
+
+extern "C" int er_meto_encode(const float* vertices, int nv, const int32_t* faces, int nf, int bins, int32_t* tokens,
+                              int32_t* n_tokens, int32_t* face_order, int32_t* face_type, int32_t* n_faces_out) {
+    if (nv < 0 || nf < 0 || bins <= 0 || !tokens || !n_tokens || !face_order || !face_type || !n_faces_out ||
+        (nv > 0 && !vertices) || (nf > 0 && !faces))
+        return fail(ER_ERR_INVALID, "er_meto_encode: bad argument");
+    for (int i = 0; i < 3 * nf; ++i)
+        if (faces[i] < 0 || faces[i] >= nv) return fail(ER_ERR_INVALID, "er_meto_encode: face index %d out of range", faces[i]);
+    const MetoEncodeOut o = meto_encode_lr_absco(vertices, nv, faces, nf, bins);
+    if ((long long)o.tokens.size() > 10LL * nf) return fail(ER_ERR_CAPACITY, "er_meto_encode: token bound exceeded");
+    memcpy(tokens, o.tokens.data(), o.tokens.size() * sizeof(int32_t));
+    memcpy(face_order, o.face_order.data(), o.face_order.size() * sizeof(int32_t));
+    memcpy(face_type, o.face_type.data(), o.face_type.size() * sizeof(int32_t));
+    *n_tokens = (int32_t)o.tokens.size();
+    *n_faces_out = (int32_t)o.face_order.size();
     return ER_OK;
 }

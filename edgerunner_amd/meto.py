@@ -1,8 +1,8 @@
 """``meto`` mesh tokenizer surface for the decode path (reference: meto/meto/__init__.py:21-54).
 
-Only what the decode path needs is native here: ``Engine(...).decode`` for the ``LR_ABSCO``
-backend (ArAE preset), implemented in C++ behind ``er_meto_decode``.  ``encode`` (training
-data / partial-mesh completion) is not built yet.
+The ``LR_ABSCO`` backend (ArAE preset) is native C++ behind ``er_meto_decode`` (the step right after
+the decode loop, row f1) and ``er_meto_encode`` (training data / partial-mesh completion, row f4),
+both bit-exact against the reference's own engine.
 Also the reference's ``detokenize_mesh`` / ``save_mesh`` (core/provider.py:39-66,112-147)
 without trimesh: meshes are ``(vertices float64 [V,3], faces int64 [F,3])`` tuples.
 """
@@ -27,8 +27,20 @@ class Engine:
         self.num_tokens = self.num_base_tokens + self.num_special_tokens
         self._lib = native.load_library()
 
-    def encode(self, vertices, faces):
-        raise NotImplementedError("meto encode is the f4 row of the scope table (not on the decode path)")
+    def encode(self, vertices, faces) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """vertices [N,3] float in [-1,1], faces [M,3] int -> (tokens, face_order, face_type)."""
+        v = np.ascontiguousarray(np.asarray(vertices, dtype=np.float32).reshape(-1, 3))
+        f = np.ascontiguousarray(np.asarray(faces, dtype=np.int32).reshape(-1, 3))
+        nf = len(f)
+        tok = np.empty((max(1, 10 * nf),), np.int32)
+        order = np.empty((max(1, nf),), np.int32)
+        ftype = np.empty((max(1, nf),), np.int32)
+        nt, no = C.c_int32(), C.c_int32()
+        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        native.check(self._lib.er_meto_encode(v.ctypes.data_as(f32p), len(v), f.ctypes.data_as(i32p), nf, self.discrete_bins,
+                                              tok.ctypes.data_as(i32p), C.byref(nt), order.ctypes.data_as(i32p),
+                                              ftype.ctypes.data_as(i32p), C.byref(no)), "er_meto_encode")
+        return (tok[: nt.value].astype(np.int64), order[: no.value].astype(np.int64), ftype[: no.value].astype(np.int64))
 
     def decode(self, tokens) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """tokens: meto ids [N] -> (vertices [V,3], faces [F,3], face_type [K])."""
@@ -51,6 +63,37 @@ def get_tokenizer(opt):
         tok = Engine(discrete_bins=opt.discrete_bins, backend=opt.meto_backend)
         return tok, tok.num_tokens + 3
     return None, opt.discrete_bins + 3
+
+
+def _canonical_faces(vertices: np.ndarray, faces: np.ndarray, keys):
+    """Shared by the tokenizer-less layout: sort vertices by `keys` (np.lexsort order), re-index the faces,
+    rotate each face so its lowest vertex comes first, sort the faces lexicographically."""
+    sort_inds = np.lexsort(keys)
+    vertices = vertices[sort_inds]
+    faces = np.argsort(sort_inds)[faces]
+    start = faces.argmin(axis=1)
+    rolled = np.take_along_axis(np.concatenate([faces, faces[:, :2]], axis=1), start[:, None] + np.arange(3)[None, :], axis=1)
+    return vertices, np.array(sorted(rolled.tolist()), dtype=faces.dtype).reshape(-1, 3)
+
+
+def tokenize_mesh(vertices, faces, discrete_bins: int, tokenizer: Optional[Engine] = None) -> np.ndarray:
+    """core/provider.py:69-110 (mesh -> model ids, without BOS/EOS): meto stream, or 9 coordinates per
+    face (vertices sorted z-y-x, faces canonicalised) when there is no tokenizer; ids are offset by 3."""
+    vertices, faces = np.asarray(vertices), np.asarray(faces)
+    if tokenizer is None:
+        vertices, faces = _canonical_faces(vertices, faces, vertices.T)
+        vertices = vertices[:, [2, 1, 0]]
+        coords = ((vertices[faces] + 1) * 0.5 * discrete_bins).clip(0, discrete_bins - 1).astype(np.int32)
+        tokens = coords.reshape(-1)
+    else:
+        tokens, _, _ = tokenizer.encode(vertices, faces)
+    return tokens + 3
+
+
+def sort_mesh(vertices, faces):
+    """meto/meto/__init__.py:93-115: vertices in y-z-x order, faces canonicalised."""
+    vertices, faces = np.asarray(vertices), np.asarray(faces)
+    return _canonical_faces(vertices, faces, (vertices[:, 0], vertices[:, 2], vertices[:, 1]))
 
 
 def detokenize_mesh(tokens, discrete_bins: Optional[int] = None, tokenizer: Optional[Engine] = None):

@@ -24,7 +24,7 @@ ER_NUM_KERNEL_KINDS = 8
 EXPORTS = [
     "er_abi_version", "er_last_error", "er_create", "er_destroy", "er_load_tensor", "er_finalize_weights",
     "er_kv_reserve", "er_encode_cond", "er_embed_tokens", "er_prefill", "er_logits", "er_feed", "er_decode",
-    "er_meto_decode", "er_kernel_kind_name", "er_profile_decode_kernels", "er_last_decode_ms",
+    "er_meto_decode", "er_meto_encode", "er_kernel_kind_name", "er_profile_decode_kernels", "er_last_decode_ms",
     "er_k_gemv", "er_k_attn_decode", "er_k_gemm", "er_k_layernorm", "er_k_softmax", "er_k_sample_head",
 ]
 
@@ -80,6 +80,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.er_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
     i32p = C.POINTER(C.c_int32)
     lib.er_meto_decode.argtypes = [i32p, ci, ci, C.POINTER(C.c_float), i32p, i32p, i32p, i32p, i32p]
+    lib.er_meto_encode.argtypes = [C.POINTER(C.c_float), ci, i32p, ci, ci, i32p, i32p, i32p, i32p, i32p]
     lib.er_k_gemv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
     lib.er_k_attn_decode.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), vp, ci, ci, ci, ci, ci, ci, vp]
     lib.er_k_gemm.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp]

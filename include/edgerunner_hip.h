@@ -146,6 +146,13 @@ int er_meto_decode(const int32_t* tokens_host, int n_tokens, int discrete_bins, 
                    int32_t* faces_out, int32_t* face_type_out, int32_t* n_vertices, int32_t* n_faces,
                    int32_t* n_face_types);
 
+/* Engine_LR_ABSCO::encode (meto/include/meto/engine_lr_absco.h:66-220) over Mesh::Mesh
+ * (meto/include/meto/mesh.h:153-262): vertices float[3*n_vertices] in [-1,1], faces int32[3*n_faces].
+ * tokens_out capacity must be >= 10*n_faces; face_order_out / face_type_out capacity >= n_faces. */
+int er_meto_encode(const float* vertices_host, int n_vertices, const int32_t* faces_host, int n_faces,
+                   int discrete_bins, int32_t* tokens_out, int32_t* n_tokens, int32_t* face_order_out,
+                   int32_t* face_type_out, int32_t* n_faces_out);
+
 /* ---- measurement ---- */
 #define ER_NUM_KERNEL_KINDS 8
 /* kinds: 0 qkv_gemv 1 attn_decode 2 attn_combine 3 out_proj_gemv 4 fc1_gemv 5 fc2_gemv 6 lm_head_gemv 7 sample_head */
