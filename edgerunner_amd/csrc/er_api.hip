@@ -1228,3 +1228,6 @@ extern "C" int er_meto_encode(const float* vertices, int nv, const int32_t* face
     *n_faces_out = (int32_t)o.face_order.size();
     return ER_OK;
 }
+
+// ------------------------------------------------------------------------------------ DiT front-end (f3)
+#include "er_dit.h"

@@ -1,0 +1,304 @@
+// DiT image-conditioned front-end behind the C ABI (er_dit_*): included at the end of er_api.hip so it can
+// reuse the prefill building blocks (linear(), attention_full(), ensure(), fail(), HIPCHK/HIPRET/ERCHK).
+// Reference: core/transformer/dit.py (DiT, DiTLayer, TimestepEmbedding) and core/models_dit.py::MDiT.run.
+#pragma once
+#include "k_dit.h"
+
+struct DitLayerW {
+    float *sst = nullptr;                                   // scale_shift_table [6][C]
+    float *qkv_w = nullptr, *qkv_b = nullptr, *o_w = nullptr, *o_b = nullptr;                     // attn1 (self)
+    float *q2_w = nullptr, *q2_b = nullptr, *k2_w = nullptr, *k2_b = nullptr, *v2_w = nullptr, *v2_b = nullptr,
+          *o2_w = nullptr, *o2_b = nullptr;                                                      // attn2 (cross)
+    float *ff0_w = nullptr, *ff0_b = nullptr, *ff2_w = nullptr, *ff2_b = nullptr;
+};
+
+struct DitSlot { float** p; size_t n; bool loaded; };
+
+struct er_dit_ctx {
+    er_dit_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    std::vector<DitLayerW> layers;
+    float *pos_embed = nullptr, *sst2 = nullptr, *proj_in_w = nullptr, *proj_in_b = nullptr, *tp1_w = nullptr, *tp1_b = nullptr,
+          *tp2_w = nullptr, *tp2_b = nullptr, *adaln_w = nullptr, *adaln_b = nullptr, *proj_out_w = nullptr,
+          *proj_out_b = nullptr, *projc_w = nullptr, *projc_b = nullptr, *normc_w = nullptr, *normc_b = nullptr;
+    std::map<std::string, DitSlot> slots;
+    std::vector<void*> owned;
+    Buf x, qkv, att, q2, kv2, u, g, sc, tin, temb0, temb1, temb, tsil, tada, gate, t_dev, xin, pred, czero, ctmp;
+};
+
+static void dit_register(er_dit_ctx* c) {
+    const er_dit_config& g = c->cfg;
+    const size_t C = g.hidden_dim;
+    auto add = [&](const std::string& k, float** p, size_t n) { c->slots[k] = DitSlot{p, n, false}; };
+    auto lin = [&](const std::string& k, float** w, float** b, size_t out, size_t in) {
+        add(k + ".weight", w, out * in);
+        add(k + ".bias", b, out);
+    };
+    add("dit.pos_embed", &c->pos_embed, (size_t)g.latent_size * C);
+    add("dit.scale_shift_table", &c->sst2, 2 * C);
+    lin("dit.proj_in", &c->proj_in_w, &c->proj_in_b, C, g.latent_dim);
+    lin("dit.timestep_proj.linear_1", &c->tp1_w, &c->tp1_b, C, 256);
+    lin("dit.timestep_proj.linear_2", &c->tp2_w, &c->tp2_b, C, C);
+    lin("dit.adaln_linear", &c->adaln_w, &c->adaln_b, 6 * C, C);
+    lin("dit.proj_out", &c->proj_out_w, &c->proj_out_b, g.latent_dim, C);
+    lin("proj_cond", &c->projc_w, &c->projc_b, C, g.clip_dim);
+    add("norm_cond.weight", &c->normc_w, C);
+    add("norm_cond.bias", &c->normc_b, C);
+    for (int i = 0; i < g.num_layers; ++i) {
+        DitLayerW& L = c->layers[i];
+        const std::string p = "dit.layers." + std::to_string(i);
+        add(p + ".scale_shift_table", &L.sst, 6 * C);
+        lin(p + ".attn1.qkv_proj", &L.qkv_w, &L.qkv_b, 3 * C, C);
+        lin(p + ".attn1.out_proj", &L.o_w, &L.o_b, C, C);
+        lin(p + ".attn2.q_proj", &L.q2_w, &L.q2_b, C, C);
+        lin(p + ".attn2.k_proj", &L.k2_w, &L.k2_b, C, C);
+        lin(p + ".attn2.v_proj", &L.v2_w, &L.v2_b, C, C);
+        lin(p + ".attn2.out_proj", &L.o2_w, &L.o2_b, C, C);
+        lin(p + ".ff.net.0", &L.ff0_w, &L.ff0_b, 8 * C, C);
+        lin(p + ".ff.net.2", &L.ff2_w, &L.ff2_b, C, 4 * C);
+    }
+}
+
+extern "C" int er_dit_create(const er_dit_config* cfg, int device, er_dit_ctx** out) {
+    if (!cfg || !out) return fail(ER_ERR_INVALID, "er_dit_create: null argument");
+    if (cfg->hidden_dim != 1024 || cfg->hidden_dim % cfg->num_heads || (cfg->hidden_dim / cfg->num_heads) % 16)
+        return fail(ER_ERR_UNSUPPORTED, "DiT width %d / heads %d not built (1024, head_dim multiple of 16)", cfg->hidden_dim, cfg->num_heads);
+    if (cfg->latent_dim % 16 || cfg->clip_dim % 16) return fail(ER_ERR_UNSUPPORTED, "latent_dim / clip_dim must be multiples of 16");
+    HIPCHK(hipSetDevice(device));
+    er_dit_ctx* c = new er_dit_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    c->layers.resize(cfg->num_layers);
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
+    dit_register(c);
+    *out = c;
+    return ER_OK;
+}
+
+extern "C" int er_dit_destroy(er_dit_ctx* c) {
+    if (!c) return ER_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void* p : c->owned) hipFree(p);
+    for (Buf* b : {&c->x, &c->qkv, &c->att, &c->q2, &c->kv2, &c->u, &c->g, &c->sc, &c->tin, &c->temb0, &c->temb1, &c->temb,
+                   &c->tsil, &c->tada, &c->gate, &c->t_dev, &c->xin, &c->pred, &c->czero, &c->ctmp})
+        if (b->p) hipFree(b->p);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return ER_OK;
+}
+
+extern "C" int er_dit_load_tensor(er_dit_ctx* c, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                                  int on_device) {
+    if (!c || !key || !data || ndim < 1 || ndim > 4) return fail(ER_ERR_INVALID, "er_dit_load_tensor: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    auto it = c->slots.find(key);
+    if (it == c->slots.end()) return 1;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    if (n != it->second.n) return fail(ER_ERR_INVALID, "er_dit_load_tensor(%s): %zu elements, expected %zu", key, n, it->second.n);
+    int err = 0;
+    std::vector<float> h = to_f32_host(data, dtype, n, on_device, &err);
+    if (err) return fail(ER_ERR_HIP, "er_dit_load_tensor(%s): device read failed", key);
+    if (!*it->second.p) {
+        HIPCHK(hipMalloc(it->second.p, n * 4));
+        c->owned.push_back(*it->second.p);
+    }
+    HIPCHK(hipMemcpy(*it->second.p, h.data(), n * 4, hipMemcpyHostToDevice));
+    it->second.loaded = true;
+    return ER_OK;
+}
+
+extern "C" int er_dit_finalize_weights(er_dit_ctx* c) {
+    if (!c) return fail(ER_ERR_INVALID, "null ctx");
+    for (auto& kv : c->slots)
+        if (!kv.second.loaded) return fail(ER_ERR_MISSING, "tensor '%s' was never loaded", kv.first.c_str());
+    return ER_OK;
+}
+
+extern "C" int er_dit_project_cond(er_dit_ctx* c, const float* clip_hidden, int B, int M, float* cond_out, void* stream) {
+    if (!c || !clip_hidden || !cond_out || B <= 0 || M <= 0) return fail(ER_ERR_INVALID, "er_dit_project_cond: bad argument");
+    ERCHK(er_dit_finalize_weights(c));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    const int C = c->cfg.hidden_dim;
+    ERCHK(ensure(c->ctmp, (size_t)B * M * C));
+    HIPRET(linear(clip_hidden, c->cfg.clip_dim, c->projc_w, c->projc_b, c->ctmp.p, C, B * M, C, c->cfg.clip_dim, false, nullptr, 0, st));
+    HIPRET(launch_layernorm(c->ctmp.p, c->normc_w, c->normc_b, cond_out, B * M, C, C, C, 1e-5f, st));
+    return ER_OK;
+}
+
+static hipError_t dit_ln_mod(const float* x, float* y, int rows, int rows_per_batch, const float* table, const float* tvec,
+                             long long t_bstride, long long t_cstride, int shift_idx, int scale_idx, hipStream_t st) {
+    hipLaunchKernelGGL((ln_modulate_rows_kernel<16>), dim3((rows + ER_NWAVES - 1) / ER_NWAVES), dim3(ER_WG), 0, st, x, y, rows,
+                       rows_per_batch, table, tvec, t_bstride, t_cstride, shift_idx, scale_idx, 1e-6f);
+    return hipGetLastError();
+}
+
+static hipError_t dit_gated_linear(const float* A, int lda, const float* W, const float* bias, float* C, int M, int N, int K,
+                                   const float* gate, int gate_rows, hipStream_t st) {   // C = C + gate_b * (A W^T + bias)
+    GemmArgs g = gemm_args_default();
+    g.A = A; g.B = W; g.C = C; g.bias = bias; g.resid = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = N; g.ldr = N;
+    g.gate = gate; g.gate_rows = gate_rows; g.gate_bstride = N;
+    return launch_gemm(g, 1, st);
+}
+
+// t_emb / t_adaln for B rows with timesteps already on the device (t_dev [B])
+static int dit_time_embed(er_dit_ctx* c, int B, hipStream_t st) {
+    const int C = c->cfg.hidden_dim;
+    ERCHK(ensure(c->tin, (size_t)B * 256));
+    ERCHK(ensure(c->temb0, (size_t)B * C));
+    ERCHK(ensure(c->temb1, (size_t)B * C));
+    ERCHK(ensure(c->temb, (size_t)B * C));
+    ERCHK(ensure(c->tsil, (size_t)B * C));
+    ERCHK(ensure(c->tada, (size_t)B * 6 * C));
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, st, c->t_dev.p, c->tin.p, B, 128);
+    HIPRET(hipGetLastError());
+    HIPRET(linear(c->tin.p, 256, c->tp1_w, c->tp1_b, c->temb0.p, C, B, C, 256, false, nullptr, 0, st));
+    hipLaunchKernelGGL(silu_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, c->temb0.p, c->temb1.p, (long long)B * C);
+    HIPRET(hipGetLastError());
+    HIPRET(linear(c->temb1.p, C, c->tp2_w, c->tp2_b, c->temb.p, C, B, C, C, false, nullptr, 0, st));
+    hipLaunchKernelGGL(silu_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, c->temb.p, c->tsil.p, (long long)B * C);
+    HIPRET(hipGetLastError());
+    HIPRET(linear(c->tsil.p, C, c->adaln_w, c->adaln_b, c->tada.p, 6 * C, B, 6 * C, C, false, nullptr, 0, st));
+    return 0;
+}
+
+// cross-attention keys/values of every layer for a fixed condition (they do not depend on x or t):
+// kv2 layout [layer][2][B*M][C]
+static int dit_cross_kv(er_dit_ctx* c, const float* cond, int B, int M, hipStream_t st) {
+    const int C = c->cfg.hidden_dim, nl = c->cfg.num_layers;
+    ERCHK(ensure(c->kv2, (size_t)nl * 2 * B * M * C));
+    for (int l = 0; l < nl; ++l) {
+        const DitLayerW& L = c->layers[l];
+        float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
+        float* v2 = k2 + (size_t)B * M * C;
+        HIPRET(linear(cond, C, L.k2_w, L.k2_b, k2, C, B * M, C, C, false, nullptr, 0, st));
+        HIPRET(linear(cond, C, L.v2_w, L.v2_b, v2, C, B * M, C, C, false, nullptr, 0, st));
+    }
+    return 0;
+}
+
+// DiT.forward body for B rows; timesteps in c->t_dev, cross K/V in c->kv2 (dit_cross_kv)
+static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float* out, hipStream_t st) {
+    const er_dit_config& g = c->cfg;
+    const int C = g.hidden_dim, N = g.latent_size, H = g.num_heads, D = C / H, LD = g.latent_dim;
+    const int R = B * N;
+    const int ldS = (N + 15) / 16 * 16;
+    ERCHK(ensure(c->x, (size_t)R * C));
+    ERCHK(ensure(c->qkv, (size_t)R * 3 * C));
+    ERCHK(ensure(c->att, (size_t)R * C));
+    ERCHK(ensure(c->q2, (size_t)R * C));
+    ERCHK(ensure(c->u, (size_t)R * 8 * C));
+    ERCHK(ensure(c->g, (size_t)R * 4 * C));
+    ERCHK(ensure(c->sc, (size_t)H * N * ldS));
+    ERCHK(ensure(c->gate, (size_t)B * C));
+    ERCHK(dit_time_embed(c, B, st));
+    float* x = c->x.p;
+    // x = proj_in(x) + pos_embed                                                  dit.py:177-180
+    HIPRET(linear(xin, LD, c->proj_in_w, c->proj_in_b, x, C, R, C, LD, false, nullptr, 0, st));
+    hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid((long long)R * C / 4)), dim3(ER_WG), 0, st, x, c->pos_embed, x, B, N, C, 0);
+    HIPRET(hipGetLastError());
+    for (int l = 0; l < g.num_layers; ++l) {
+        const DitLayerW& L = c->layers[l];
+        // x = norm1(x) * (1 + scale_msa) + shift_msa   (chunks 0 = shift, 1 = scale, 2 = gate)     dit.py:129-132
+        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st));
+        // x = x + gate_msa * attn1(x)                                               dit.py:133
+        HIPRET(linear(x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, false, nullptr, 0, st));
+        for (int b = 0; b < B; ++b) {
+            float* base = c->qkv.p + (size_t)b * N * 3 * C;
+            ERCHK(attention_full(base, 3 * C, base + C, 3 * C, D, base + 2 * C, 3 * C, D, c->att.p + (size_t)b * N * C, C, c->sc.p,
+                                 H, D, N, N, false, st));
+        }
+        hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 2);
+        HIPRET(hipGetLastError());
+        HIPRET(dit_gated_linear(c->att.p, C, L.o_w, L.o_b, x, R, C, C, c->gate.p, N, st));
+        // x = x + attn2(x, c)                                                       dit.py:135
+        HIPRET(linear(x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, false, nullptr, 0, st));
+        const float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
+        const float* v2 = k2 + (size_t)B * M * C;
+        for (int b = 0; b < B; ++b)
+            ERCHK(attention_full(c->q2.p + (size_t)b * N * C, C, k2 + (size_t)b * M * C, C, D, v2 + (size_t)b * M * C, C, D,
+                                 c->att.p + (size_t)b * N * C, C, c->sc.p, H, D, N, M, false, st));
+        HIPRET(linear(c->att.p, C, L.o2_w, L.o2_b, x, C, R, C, C, false, x, C, st));
+        // x = norm2(x) * (1 + scale_mlp) + shift_mlp; x = x + gate_mlp * ff(x)     dit.py:137-139
+        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 3, 4, st));
+        HIPRET(linear(x, C, L.ff0_w, L.ff0_b, c->u.p, 8 * C, R, 8 * C, C, false, nullptr, 0, st));
+        hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)R * 4 * C)), dim3(ER_WG), 0, st, c->u.p, c->g.p, (long long)R, 4 * C);
+        HIPRET(hipGetLastError());
+        hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 5);
+        HIPRET(hipGetLastError());
+        HIPRET(dit_gated_linear(c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, R, C, 4 * C, c->gate.p, N, st));
+    }
+    // shift, scale = scale_shift_table + t_emb; x = norm_out(x) * (1 + scale) + shift; proj_out     dit.py:190-194
+    HIPRET(dit_ln_mod(x, x, R, N, c->sst2, c->temb.p, (long long)C, 0, 0, 1, st));
+    HIPRET(linear(x, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, false, nullptr, 0, st));
+    return 0;
+}
+
+extern "C" int er_dit_forward(er_dit_ctx* c, const float* x, const float* cond, const float* t_host, int B, int M, float* out,
+                              void* stream) {
+    if (!c || !x || !cond || !t_host || !out || B <= 0 || M <= 0) return fail(ER_ERR_INVALID, "er_dit_forward: bad argument");
+    ERCHK(er_dit_finalize_weights(c));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    ERCHK(ensure(c->t_dev, (size_t)B));
+    HIPCHK(hipMemcpyAsync(c->t_dev.p, t_host, B * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ERCHK(dit_cross_kv(c, cond, B, M, st));
+    return dit_forward_impl(c, x, B, M, out, st) < 0 ? -1 : ER_OK;
+}
+
+extern "C" int er_dit_sample(er_dit_ctx* c, const float* cond, int B, int M, float* latents, int steps, float guidance,
+                             void* stream) {
+    if (!c || !cond || !latents || B <= 0 || M <= 0 || steps <= 0 || steps > 1000)
+        return fail(ER_ERR_INVALID, "er_dit_sample: bad argument");
+    ERCHK(er_dit_finalize_weights(c));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    const er_dit_config& g = c->cfg;
+    const int C = g.hidden_dim, N = g.latent_size, LD = g.latent_dim;
+    const size_t nlat = (size_t)B * N * LD;
+    // DDIM tables (diffusers DDIMScheduler: scaled_linear betas in fp32, cumprod, leading spacing + offset 1)
+    const int T = 1000;
+    std::vector<float> ac(T);
+    {
+        // torch.linspace(sqrt(b0), sqrt(b1), T, fp32) ** 2 -> cumprod(1 - betas), all in fp32 like diffusers
+        const float lo = (float)sqrt(0.00085), hi = (float)sqrt(0.012);
+        const float step = (hi - lo) / (float)(T - 1);
+        float prod = 1.0f;
+        for (int i = 0; i < T; ++i) {
+            const float r = (i < T / 2) ? lo + step * (float)i : hi - step * (float)(T - 1 - i);   // linspace is symmetric
+            const float beta = r * r;
+            prod *= (1.0f - beta);
+            ac[i] = prod;
+        }
+    }
+    const int ratio = T / steps;
+    // CFG batch: rows [0,B) = zero condition, rows [B,2B) = cond                   models_dit.py:211
+    ERCHK(ensure(c->czero, (size_t)2 * B * M * C));
+    HIPCHK(hipMemsetAsync(c->czero.p, 0, (size_t)B * M * C * 4, st));
+    HIPCHK(hipMemcpyAsync(c->czero.p + (size_t)B * M * C, cond, (size_t)B * M * C * 4, hipMemcpyDeviceToDevice, st));
+    ERCHK(dit_cross_kv(c, c->czero.p, 2 * B, M, st));
+    ERCHK(ensure(c->xin, 2 * nlat));
+    ERCHK(ensure(c->pred, 2 * nlat));
+    ERCHK(ensure(c->t_dev, (size_t)2 * B));
+    std::vector<float> th(2 * B);
+    for (int i = steps - 1; i >= 0; --i) {
+        const int t = i * ratio + 1;
+        for (int b = 0; b < 2 * B; ++b) th[b] = (float)t;
+        HIPCHK(hipMemcpyAsync(c->t_dev.p, th.data(), 2 * B * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->xin.p, latents, nlat * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->xin.p + nlat, latents, nlat * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));      // th is reused next iteration
+        if (dit_forward_impl(c, c->xin.p, 2 * B, M, c->pred.p, st) < 0) return -1;
+        const int prev = t - ratio;
+        const float a_t = ac[t], a_p = prev >= 0 ? ac[prev] : ac[0];
+        hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3((unsigned)((nlat + 255) / 256)), dim3(256), 0, st, latents, c->pred.p,
+                           (long long)nlat, guidance, sqrtf(a_t), sqrtf(1.0f - a_t), sqrtf(a_p), sqrtf(1.0f - a_p));
+        HIPRET(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return ER_OK;
+}

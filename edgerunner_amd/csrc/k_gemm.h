@@ -22,6 +22,9 @@ struct GemmArgs {
     const float* A; const float* B; float* C;
     const float* bias;        // [N] or null
     const float* resid;       // [M][ldr] or null (added last)
+    const float* gate;        // or null: per-(batch,column) multiplier applied before the residual add:
+    int gate_rows;            //   v = resid + gate[(m / gate_rows) * gate_bstride + n] * (acc + bias)   (adaLN gates)
+    long long gate_bstride;
     int M, N, K;              // K % 16 == 0; A must be readable (and zero-padded) up to K
     int lda, ldb, ldc, ldr;
     long long sA1, sA2, sB1, sB2, sC1, sC2;   // offsets = (z / Z2) * s?1 + (z % Z2) * s?2
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
                 if (g.div != 0.f) v = v / g.div;
                 if (g.bias) v += g.bias[gn];
                 if (g.relu) v = fmaxf(v, 0.f);
+                if (g.gate) v *= g.gate[(long long)(gm / g.gate_rows) * g.gate_bstride + gn];
                 if (g.resid) v += g.resid[(long long)gm * g.ldr + gn];
                 if (g.epi == GEPI_PLAIN) {
                     C[(long long)gm * g.ldc + gn] = v;

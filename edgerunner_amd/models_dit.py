@@ -1,0 +1,131 @@
+"""``MDiT`` - the image-conditioned diffusion front-end of the reference (core/models_dit.py:34-229) on
+MI355X: projected image condition -> DiT denoiser (core/transformer/dit.py) sampled with DDIM +
+classifier-free guidance -> latents ``[B, 2048, 64]`` that ``LMM.generate`` consumes in
+``cond_mode='point_latent'`` (infer_dit.py:55,111-113).
+
+Built: ``proj_cond``/``norm_cond`` (get_cond after the image encoder), ``DiT.forward``, ``run`` (latents=None).
+Not built: the CLIP ViT-H/14 image encoder itself (``image_encoder.*``; frozen third-party model whose
+weights cannot be fetched here) - ``get_cond`` therefore takes the encoder's ``last_hidden_state``
+``[B, 257, 1280]``; training ``forward`` and the img2img branch (``latents`` given) are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import native
+
+CLIP_DIM = 1280   # laion/CLIP-ViT-H-14 hidden width (core/models_dit.py:56)
+
+
+class MDiT:
+    def __init__(self, opt, device="cuda:0"):
+        self.opt = opt
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise native.NativeError("MDiT needs a HIP device; there is no CPU fallback")
+        self.lib = native.load_library()
+        cfg = native.ErDitConfig(hidden_dim=opt.dit_hidden_dim, num_heads=opt.dit_num_heads, num_layers=opt.dit_num_layers,
+                                 latent_size=opt.point_latent_size, latent_dim=opt.point_latent_dim, clip_dim=CLIP_DIM)
+        self._ctx = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        native.check(self.lib.er_dit_create(C.byref(cfg), idx, C.byref(self._ctx)), "er_dit_create")
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self.lib.er_dit_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # nn.Module-shaped conveniences (infer_dit.py:61-71)
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        unexpected = []
+        for key, t in sd.items():
+            t = t.detach().float().contiguous() if t.dtype not in (torch.float32, torch.float16, torch.bfloat16) else t.detach().contiguous()
+            dt = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[t.dtype]
+            shape = (C.c_int64 * max(1, t.dim()))(*(list(t.shape) or [1]))
+            rc = native.check(self.lib.er_dit_load_tensor(self._ctx, key.encode(), native.ptr(t), dt, max(1, t.dim()), shape,
+                                                          1 if t.is_cuda else 0), f"er_dit_load_tensor({key})")
+            if rc == 1:
+                unexpected.append(key)
+        rc = self.lib.er_dit_finalize_weights(self._ctx)
+        missing = [self.lib.er_last_error().decode()] if rc < 0 else []
+        if strict and (missing or unexpected):
+            raise native.NativeError(f"missing={missing} unexpected={unexpected[:4]}")
+        return missing, unexpected
+
+    def half(self):
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def _sync_in(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _sync_out(self):
+        self.stream.synchronize()
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def _sp(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    @torch.no_grad()
+    def get_cond(self, inputs: torch.Tensor) -> torch.Tensor:
+        """core/models_dit.py:104-115 from the image encoder's last_hidden_state [B, 257, 1280]."""
+        if inputs.dim() != 3 or inputs.shape[-1] != CLIP_DIM:
+            raise NotImplementedError("the CLIP ViT-H/14 image encoder is not built: pass its last_hidden_state "
+                                      f"[B, 257, {CLIP_DIM}] (got {tuple(inputs.shape)})")
+        x = inputs.to(self.device, torch.float32).contiguous()
+        self._sync_in()
+        with torch.cuda.stream(self.stream):
+            out = torch.empty((x.shape[0], x.shape[1], self.opt.dit_hidden_dim), dtype=torch.float32, device=self.device)
+            native.check(self.lib.er_dit_project_cond(self._ctx, native.ptr(x), x.shape[0], x.shape[1], native.ptr(out), self._sp()),
+                         "er_dit_project_cond")
+        self._sync_out()
+        return out
+
+    @torch.no_grad()
+    def dit(self, x: torch.Tensor, c: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """DiT.forward(x, c, t) (core/transformer/dit.py:168-196)."""
+        x = x.to(self.device, torch.float32).contiguous()
+        c = c.to(self.device, torch.float32).contiguous()
+        th = (C.c_float * x.shape[0])(*[float(v) for v in t.flatten().tolist()])
+        self._sync_in()
+        with torch.cuda.stream(self.stream):
+            out = torch.empty_like(x)
+            native.check(self.lib.er_dit_forward(self._ctx, native.ptr(x), native.ptr(c), th, x.shape[0], c.shape[1], native.ptr(out),
+                                                 self._sp()), "er_dit_forward")
+        self._sync_out()
+        return out
+
+    @torch.no_grad()
+    def run(self, inputs, num_inference_steps=100, guidance_scale=7.5, num_repeat=1, latents=None, strength=0.5,
+            noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """core/models_dit.py:184-229.  ``noise``: the initial Gaussian latents (default: torch.randn on the
+        device, like the reference); pass it explicitly to reproduce a CPU run."""
+        if latents is not None:
+            raise NotImplementedError("img2img branch (latents given) is not built")
+        cond = self.get_cond(inputs)
+        cond = cond.repeat_interleave(num_repeat, dim=0).contiguous()
+        B = cond.shape[0]
+        if noise is None:
+            noise = torch.randn(B, self.opt.point_latent_size, self.opt.point_latent_dim, device=self.device, dtype=torch.float32)
+        lat = noise.to(self.device, torch.float32).contiguous().clone()
+        self._sync_in()
+        with torch.cuda.stream(self.stream):
+            native.check(self.lib.er_dit_sample(self._ctx, native.ptr(cond), B, cond.shape[1], native.ptr(lat),
+                                                int(num_inference_steps), float(guidance_scale), self._sp()), "er_dit_sample")
+        self._sync_out()
+        return lat

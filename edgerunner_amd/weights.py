@@ -206,3 +206,42 @@ def synthetic_point_cloud(index: int, num_points: int = 4096) -> torch.Tensor:
     g = torch.Generator(device="cpu")
     g.manual_seed(1000 + int(index))
     return (torch.rand(num_points, 3, generator=g, dtype=torch.float32) * 1.9 - 0.95).unsqueeze(0)
+
+
+# ------------------------------------------------------------------------------------ DiT front-end (f3)
+def dit_tensor_specs(opt, clip_dim: int = 1280) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(key, shape, kind) of the MDiT checkpoint entries the denoiser reads (core/models_dit.py:43-63 /
+    core/transformer/dit.py:143-166); init kinds follow the reference constructors (torch default Linear
+    init, randn/sqrt(dim) tables)."""
+    C, L, N = opt.dit_hidden_dim, opt.point_latent_dim, opt.point_latent_size
+    specs: List[Tuple[str, Tuple[int, ...], str]] = []
+
+    def linear(prefix, out_f, in_f):
+        specs.append((f"{prefix}.weight", (out_f, in_f), f"linear_w:{in_f}"))
+        specs.append((f"{prefix}.bias", (out_f,), f"bias:{in_f}"))
+
+    specs.append(("dit.pos_embed", (1, N, C), f"normal:{1.0 / math.sqrt(C)}"))
+    specs.append(("dit.scale_shift_table", (2, C), f"normal:{1.0 / math.sqrt(C)}"))
+    linear("dit.proj_in", C, L)
+    linear("dit.timestep_proj.linear_1", C, 256)
+    linear("dit.timestep_proj.linear_2", C, C)
+    linear("dit.adaln_linear", 6 * C, C)
+    for i in range(opt.dit_num_layers):
+        p = f"dit.layers.{i}"
+        specs.append((f"{p}.scale_shift_table", (6, C), f"normal:{1.0 / math.sqrt(C)}"))
+        linear(f"{p}.attn1.qkv_proj", 3 * C, C)
+        linear(f"{p}.attn1.out_proj", C, C)
+        for q in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            linear(f"{p}.attn2.{q}", C, C)
+        linear(f"{p}.ff.net.0", 8 * C, C)
+        linear(f"{p}.ff.net.2", C, 4 * C)
+    linear("dit.proj_out", L, C)
+    linear("proj_cond", C, clip_dim)
+    specs.append(("norm_cond.weight", (C,), "ln_w"))
+    specs.append(("norm_cond.bias", (C,), "ln_b"))
+    return specs
+
+
+def make_dit_state_dict(opt, seed: int = 0, style: str = "perturbed") -> Dict[str, torch.Tensor]:
+    # encoder-style biases (torch default) in both styles: keys do not start with "mesh_decoder"
+    return {k: make_tensor("mdit." + k, shape, kind, seed, style) for k, shape, kind in dit_tensor_specs(opt)}

@@ -153,6 +153,34 @@ int er_meto_encode(const float* vertices_host, int n_vertices, const int32_t* fa
                    int discrete_bins, int32_t* tokens_out, int32_t* n_tokens, int32_t* face_order_out,
                    int32_t* face_type_out, int32_t* n_faces_out);
 
+/* ---- DiT image-conditioned front-end (scope row f3): core/transformer/dit.py + core/models_dit.py::MDiT ----
+ * Produces the latents [B, latent_size, latent_dim] that LMM.generate consumes in cond_mode 'point_latent'
+ * (infer_dit.py:55,111-113).  fp32, built from the prefill kernels (MFMA GEMM, row softmax) plus k_dit.h. */
+typedef struct {
+    int32_t hidden_dim, num_heads, num_layers;   /* Options.dit_hidden_dim / dit_num_heads / dit_num_layers */
+    int32_t latent_size, latent_dim;             /* point_latent_size (2048), point_latent_dim (64)          */
+    int32_t clip_dim;                            /* width of the image encoder's last_hidden_state (1280)   */
+} er_dit_config;
+typedef struct er_dit_ctx er_dit_ctx;
+int er_dit_create(const er_dit_config* cfg, int device, er_dit_ctx** out);
+int er_dit_destroy(er_dit_ctx* ctx);
+/* MDiT checkpoint keys: "dit.*", "proj_cond.*", "norm_cond.*" (others - image_encoder.*, point_encoder.* - are ignored: returns 1) */
+int er_dit_load_tensor(er_dit_ctx* ctx, const char* key, const void* data, int dtype, int ndim,
+                       const int64_t* shape, int on_device);
+int er_dit_finalize_weights(er_dit_ctx* ctx);
+/* MDiT.get_cond after the image encoder: cond = norm_cond(proj_cond(clip_hidden))   core/models_dit.py:113
+ * clip_hidden_dev float[B, M, clip_dim] -> cond_out_dev float[B, M, hidden_dim] */
+int er_dit_project_cond(er_dit_ctx* ctx, const float* clip_hidden_dev, int batch, int m_tokens,
+                        float* cond_out_dev, void* stream);
+/* DiT.forward(x, c, t)   core/transformer/dit.py:168-196: x float[B,N,latent_dim], c float[B,M,hidden], t_host float[B] */
+int er_dit_forward(er_dit_ctx* ctx, const float* x_dev, const float* c_dev, const float* t_host, int batch,
+                   int m_tokens, float* out_dev, void* stream);
+/* MDiT.run's denoise loop (core/models_dit.py:184-229, num_repeat = 1): DDIM (v-prediction, scaled-linear betas
+ * 0.00085..0.012, leading spacing, steps_offset 1, eta 0) with classifier-free guidance over [zeros | cond];
+ * latents_dev float[B, N, latent_dim] holds the initial Gaussian noise on entry and the result on exit. */
+int er_dit_sample(er_dit_ctx* ctx, const float* cond_dev, int batch, int m_tokens, float* latents_dev,
+                  int num_inference_steps, float guidance_scale, void* stream);
+
 /* ---- measurement ---- */
 #define ER_NUM_KERNEL_KINDS 8
 /* kinds: 0 qkv_gemv 1 attn_decode 2 attn_combine 3 out_proj_gemv 4 fc1_gemv 5 fc2_gemv 6 lm_head_gemv 7 sample_head */

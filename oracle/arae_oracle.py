@@ -30,6 +30,7 @@ from __future__ import annotations
 import math
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -354,3 +355,109 @@ def lmm_generate_ids(sd: StateDict, opt, conds, num_faces: int = 1000, resume_id
         max_new_tokens = opt.max_seq_length                                   # :278
     return generate(fwd or make_forward(sd, opt), opt, emb, max_new_tokens, mode=opt.generate_mode, allowed_fns=fns,
                     min_new_tokens=min_new_tokens, **kw)
+
+
+# ============================================================================= DiT front-end (scope row f3)
+# Restatement of core/transformer/dit.py::DiT (adaLN-single, PixArt-alpha style) at state_dict level
+# (prefix "dit.") and of MDiT.run's sampling loop (core/models_dit.py:184-229).  The scheduler is
+# diffusers' DDIMScheduler (third-party, absent here: diffusers is in requirements.txt but not vendored);
+# its published update rule is restated in ddim_* below for the reference's configuration
+# (core/models_dit.py:91-102: v_prediction, scaled_linear betas 0.00085..0.012, 1000 train steps,
+# "leading" spacing, steps_offset 1, set_alpha_to_one False, eta 0, no clipping) - unpinned by upstream tests.
+def timestep_embedding(t, num_channels=256, max_period=10000):
+    """dit.py:45-77 (Timesteps, flip_sin_to_cos=False, shift 0, scale 1)."""
+    half = num_channels // 2
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
+    exponent = exponent / half
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+
+
+def _mha(sd, prefix, xq, ctx, num_heads, fused_qkv):
+    """SelfAttention (attention.py:98-121, fused qkv_proj) / CrossAttention (:124-153)."""
+    B, N, C = xq.shape
+    D = C // num_heads
+    if fused_qkv:
+        qkv = _lin(sd, f"{prefix}.qkv_proj", xq).reshape(B, N, 3, num_heads, D).permute(2, 0, 1, 3, 4)
+        q, k, v = qkv.chunk(3, dim=0)
+        q, k, v = q[0], k[0], v[0]
+    else:
+        M = ctx.shape[1]
+        q = _lin(sd, f"{prefix}.q_proj", xq).reshape(B, N, num_heads, D)
+        k = _lin(sd, f"{prefix}.k_proj", ctx).reshape(B, M, num_heads, D)
+        v = _lin(sd, f"{prefix}.v_proj", ctx).reshape(B, M, num_heads, D)
+    a = attention_naive(q, k, v, causal=False)
+    return _lin(sd, f"{prefix}.out_proj", a.reshape(B, N, -1))
+
+
+def dit_forward(sd: StateDict, x, c, t, num_heads: int, prefix="dit"):
+    """DiT.forward (dit.py:168-196) with DiTLayer._forward (:123-140).  x [B,N,latent], c [B,M,C], t [B]."""
+    B = x.shape[0]
+    x = _lin(sd, f"{prefix}.proj_in", x) + sd[f"{prefix}.pos_embed"]
+    t_emb = timestep_embedding(t)
+    t_emb = _lin(sd, f"{prefix}.timestep_proj.linear_2", F.silu(_lin(sd, f"{prefix}.timestep_proj.linear_1", t_emb)))
+    t_adaln = _lin(sd, f"{prefix}.adaln_linear", F.silu(t_emb)).view(B, 6, -1)
+    C = x.shape[-1]
+    i = 0
+    while f"{prefix}.layers.{i}.scale_shift_table" in sd:
+        L = f"{prefix}.layers.{i}"
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = (sd[f"{L}.scale_shift_table"][None] + t_adaln).chunk(6, dim=1)
+        h = F.layer_norm(x, (C,), None, None, 1e-6)
+        h = h * (1 + sc_a) + sh_a
+        h = h + g_a * _mha(sd, f"{L}.attn1", h, None, num_heads, True)       # NB: residual is the MODULATED input (dit.py:133-135)
+        h = h + _mha(sd, f"{L}.attn2", h, c, num_heads, False)
+        x = F.layer_norm(h, (C,), None, None, 1e-6)
+        x = x * (1 + sc_m) + sh_m
+        x = x + g_m * _lin(sd, f"{L}.ff.net.2", (lambda u: u[0] * F.gelu(u[1]))(_lin(sd, f"{L}.ff.net.0", x).chunk(2, dim=-1)))
+        i += 1
+    shift, scale = (sd[f"{prefix}.scale_shift_table"][None] + t_emb[:, None]).chunk(2, dim=1)
+    x = F.layer_norm(x, (C,), None, None, 1e-6)
+    x = x * (1 + scale) + shift
+    return _lin(sd, f"{prefix}.proj_out", x)
+
+
+def ddim_schedule(num_inference_steps=100, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+    """diffusers DDIMScheduler.__init__/set_timesteps for the reference's config: returns (timesteps list,
+    alphas_cumprod fp32 tensor, final_alpha_cumprod)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    ratio = num_train // num_inference_steps
+    ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + steps_offset
+    return ts.tolist(), ac, ac[0]
+
+
+def ddim_step_v(sample, v, t, ac, final_ac, ratio):
+    """DDIMScheduler.step, prediction_type='v_prediction', eta=0, clip_sample=False."""
+    prev = t - ratio
+    a_t = ac[t]
+    a_prev = ac[prev] if prev >= 0 else final_ac
+    b_t = 1 - a_t
+    pred_x0 = (a_t ** 0.5) * sample - (b_t ** 0.5) * v
+    pred_eps = (a_t ** 0.5) * v + (b_t ** 0.5) * sample
+    return (a_prev ** 0.5) * pred_x0 + ((1 - a_prev) ** 0.5) * pred_eps
+
+
+def dit_project_cond(sd: StateDict, clip_hidden):
+    """MDiT.get_cond after the CLIP encoder (core/models_dit.py:113)."""
+    return _ln(sd, "norm_cond", _lin(sd, "proj_cond", clip_hidden))
+
+
+@torch.no_grad()
+def mdit_run(sd: StateDict, cond, init_latents, num_heads: int, num_inference_steps=100, guidance_scale=7.5,
+             forward_fn=None):
+    """MDiT.run (core/models_dit.py:184-229) from projected cond [B,M,C] and the initial noise the reference
+    draws with torch.randn (passed in, RNG streams do not transfer across devices); num_repeat = 1."""
+    fwd = forward_fn or (lambda x, c, t: dit_forward(sd, x, c, t, num_heads))
+    ts, ac, final = ddim_schedule(num_inference_steps)
+    ratio = 1000 // num_inference_steps
+    B = cond.shape[0]
+    latents = init_latents.clone()
+    c2 = torch.cat([torch.zeros_like(cond), cond], dim=0)
+    for t in ts:
+        x2 = torch.cat([latents] * 2, dim=0)
+        t_in = torch.tensor([t] * B * 2, dtype=latents.dtype)
+        pred = fwd(x2, c2, t_in)
+        u, cnd = pred.chunk(2)
+        pred = u + guidance_scale * (cnd - u)
+        latents = ddim_step_v(latents, pred, t, ac, final, ratio)
+    return latents

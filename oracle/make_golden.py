@@ -208,6 +208,49 @@ def make_eos():
 
 
 @torch.no_grad()
+def make_dit():
+    """DiT front-end (f3): the reference's own DiT module (2 layers, full width) on the synthetic MDiT
+    checkpoint: one forward, a 6-step CFG/DDIM sampling run (restated scheduler), then the latents through
+    the reference LMM in point_latent mode."""
+    from core.transformer.dit import DiT as RefDiT
+    opt, ref_opt = opts(2, generate_mode="greedy", cond_mode="point_latent", dit_num_layers=2)
+    sd_d = W.make_dit_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE)
+    dit = RefDiT(hidden_dim=opt.dit_hidden_dim, num_heads=opt.dit_num_heads, latent_size=opt.point_latent_size,
+                 latent_dim=opt.point_latent_dim, num_layers=2, gradient_checkpointing=False).eval()
+    missing, unexpected = dit.load_state_dict({k[4:]: v for k, v in sd_d.items() if k.startswith("dit.")}, strict=True)
+    g = torch.Generator().manual_seed(314)
+    clip_hidden = torch.randn(1, 257, 1280, generator=g)
+    noise = torch.randn(1, 2048, 64, generator=g)
+    cond = O.dit_project_cond(sd_d, clip_hidden)
+    x = torch.randn(2, 2048, 64, generator=g)
+    c2 = torch.cat([torch.zeros_like(cond), cond])
+    t = torch.tensor([991.0, 501.0])
+    y_ref = dit(x, c2, t)
+    y_mine = O.dit_forward(sd_d, x, c2, t, opt.dit_num_heads)
+    ok = torch.equal(y_ref, y_mine)
+    print("DiT restatement bit-identical to the reference module:", ok)
+    assert ok
+    lat = O.mdit_run(sd_d, cond, noise, opt.dit_num_heads, num_inference_steps=6, guidance_scale=7.5,
+                     forward_fn=lambda a, b, c_: dit(a, b, c_))
+    lat2 = O.mdit_run(sd_d, cond, noise, opt.dit_num_heads, num_inference_steps=6, guidance_scale=7.5)
+    assert torch.equal(lat, lat2)
+    rows = [0, 1, 1000, 2047]
+    out = {"seed": np.array([314]), "rows": np.array(rows), "t": t.numpy(),
+           "cond_rows": cond[0, [0, 100, 256]].numpy(), "fwd_rows": y_ref[:, rows].numpy(),
+           "fwd_sum": np.array([float(y_ref.double().sum()), float(y_ref.double().abs().sum())]),
+           "lat_rows": lat[0, rows].numpy(), "lat_sum": np.array([float(lat.double().sum()), float(lat.double().abs().sum())])}
+    # latents -> ArAE decode (point_latent conditioning), reference LMM modules
+    sd = {k: v for k, v in W.make_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE).items()}
+    model = build_reference(ref_opt, sd)
+    out["ids_from_latents"], _ = run_case(model, sd, opt, lat, 1000, 32, 32)
+    np.savez_compressed(os.path.join(GOLD, "dit_small.npz"), **out)
+    manifest_update("dit_small", {"dit_num_layers": 2, "restatement_bit_identical": bool(ok), "steps": 6,
+                                  "scheduler": "restated diffusers DDIMScheduler (absent), config core/models_dit.py:91-102",
+                                  "cases": {k: list(v.shape) for k, v in out.items()}})
+    print({k: v.shape for k, v in out.items()})
+
+
+@torch.no_grad()
 def make_full(T=4000):
     """BASELINE configs[0]/[1]: ArAE 24 layers, cloud 0 (4096 pts), greedy,
     test_num_face=1000, T=4000 new tokens with EOS suppressed until T."""
@@ -256,6 +299,8 @@ if __name__ == "__main__":
         make_small()
     elif what == "eos":
         make_eos()
+    elif what == "dit":
+        make_dit()
     elif what == "full":
         make_full(int(sys.argv[2]) if len(sys.argv) > 2 else 4000)
     else:

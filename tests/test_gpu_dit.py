@@ -1,0 +1,83 @@
+"""DiT image-conditioned front-end (scope row f3) through the C ABI (er_dit_*) against goldens produced by the
+reference's own DiT module (oracle/make_golden.py dit) and against the oracle live.  fp32: 1e-3 on latents
+(they are O(1); a 6-step CFG sampler amplifies round-off), ids of the downstream ArAE decode exact."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_small.npz")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models_dit import MDiT
+    from edgerunner_amd.options import config_defaults
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=2, generate_mode="greedy", cond_mode="point_latent",
+                              dit_num_layers=2)
+    sd = W.make_dit_state_dict(opt, 0, "perturbed")
+    m = MDiT(opt, DEV)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    g = dict(np.load(GOLD))
+    gen = torch.Generator().manual_seed(int(g["seed"][0]))
+    clip_hidden = torch.randn(1, 257, 1280, generator=gen)
+    noise = torch.randn(1, 2048, 64, generator=gen)
+    x = torch.randn(2, 2048, 64, generator=gen)
+    return opt, sd, m, g, clip_hidden, noise, x
+
+
+def test_project_cond_and_forward_vs_reference_module(setup):
+    opt, sd, m, g, clip_hidden, noise, x = setup
+    cond = m.get_cond(clip_hidden.to(DEV))
+    err = np.abs(cond[0, [0, 100, 256]].cpu().numpy() - g["cond_rows"]).max()
+    assert err < 1e-4, err
+    c2 = torch.cat([torch.zeros_like(cond), cond])
+    y = m.dit(x.to(DEV), c2, torch.tensor(g["t"]))
+    rows = g["rows"].tolist()
+    err = np.abs(y[:, rows].cpu().numpy() - g["fwd_rows"]).max()
+    rel = abs(float(y.double().sum()) - g["fwd_sum"][0]) / g["fwd_sum"][1]
+    print(f"DiT forward: max abs err on sampled rows {err:.3e}, checksum rel err {rel:.3e}")
+    assert err < 1e-3 and rel < 1e-5
+
+
+def test_sampler_vs_reference_and_downstream_decode(setup):
+    opt, sd, m, g, clip_hidden, noise, x = setup
+    lat = m.run(clip_hidden.to(DEV), num_inference_steps=6, guidance_scale=7.5, noise=noise.to(DEV))
+    rows = g["rows"].tolist()
+    err = np.abs(lat[0, rows].cpu().numpy() - g["lat_rows"]).max()
+    rel = abs(float(lat.double().sum()) - g["lat_sum"][0]) / g["lat_sum"][1]
+    print(f"6-step CFG/DDIM latents: max abs err {err:.3e}, checksum rel err {rel:.3e}")
+    assert err < 2e-3 and rel < 1e-4
+    # latents -> ArAE decode in point_latent mode (infer_dit.py:111-113)
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models import LMM
+    lmm = LMM(opt, DEV)
+    lmm.mesh_decoder.load_state_iter(W.iter_state_dict(opt, 0, "perturbed"), strict=True)
+    _, toks = lmm.generate(lat, 1000, tokenizer=object(), max_new_tokens=32, min_new_tokens=32)
+    assert np.array_equal(toks[0], g["ids_from_latents"][0]), (toks[0], g["ids_from_latents"][0])
+
+
+def test_sampler_vs_oracle_live_batch2(setup):
+    import arae_oracle as O
+    opt, sd, m, g, clip_hidden, noise, x = setup
+    gen = torch.Generator().manual_seed(99)
+    ch = torch.randn(2, 257, 1280, generator=gen)
+    nz = torch.randn(2, 2048, 64, generator=gen)
+    want = O.mdit_run(sd, O.dit_project_cond(sd, ch), nz, opt.dit_num_heads, num_inference_steps=3, guidance_scale=5.0)
+    got = m.run(ch.to(DEV), num_inference_steps=3, guidance_scale=5.0, noise=nz.to(DEV)).cpu()
+    err = float((got - want).abs().max())
+    print(f"3-step sampler, batch 2: max abs err {err:.3e}")
+    assert err < 2e-3
+
+
+def test_unbuilt_pieces_fail_loudly(setup):
+    opt, sd, m, g, clip_hidden, noise, x = setup
+    with pytest.raises(NotImplementedError, match="image encoder"):
+        m.get_cond(torch.rand(1, 3, 512, 512))
+    with pytest.raises(NotImplementedError):
+        m.run(clip_hidden.to(DEV), latents=noise.to(DEV))
