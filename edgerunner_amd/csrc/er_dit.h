@@ -12,6 +12,12 @@ struct DitLayerW {
     float *ff0_w = nullptr, *ff0_b = nullptr, *ff2_w = nullptr, *ff2_b = nullptr;
 };
 
+struct ClipLayerW {
+    float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+    float *qw = nullptr, *qb = nullptr, *kw = nullptr, *kb = nullptr, *vw = nullptr, *vb = nullptr, *ow = nullptr, *ob = nullptr;
+    float *f1w = nullptr, *f1b = nullptr, *f2w = nullptr, *f2b = nullptr;
+};
+
 struct DitSlot { float** p; size_t n; bool loaded; };
 
 struct er_dit_ctx {
@@ -22,6 +28,10 @@ struct er_dit_ctx {
     float *pos_embed = nullptr, *sst2 = nullptr, *proj_in_w = nullptr, *proj_in_b = nullptr, *tp1_w = nullptr, *tp1_b = nullptr,
           *tp2_w = nullptr, *tp2_b = nullptr, *adaln_w = nullptr, *adaln_b = nullptr, *proj_out_w = nullptr,
           *proj_out_b = nullptr, *projc_w = nullptr, *projc_b = nullptr, *normc_w = nullptr, *normc_b = nullptr;
+    std::vector<ClipLayerW> clip;
+    float *clip_cls = nullptr, *clip_patch_w = nullptr, *clip_pos = nullptr, *clip_prew = nullptr, *clip_preb = nullptr;
+    int clip_kpad = 0;
+    Buf cpx, ccol, cpatch, cx, ch, cq, ck, cv, catt, cf;
     std::map<std::string, DitSlot> slots;
     std::vector<void*> owned;
     Buf x, qkv, att, q2, kv2, u, g, sc, tin, temb0, temb1, temb, tsil, tada, gate, t_dev, xin, pred, czero, ctmp;
@@ -45,6 +55,28 @@ static void dit_register(er_dit_ctx* c) {
     lin("proj_cond", &c->projc_w, &c->projc_b, C, g.clip_dim);
     add("norm_cond.weight", &c->normc_w, C);
     add("norm_cond.bias", &c->normc_b, C);
+    if (g.clip_layers > 0) {
+        const std::string p = "image_encoder.vision_model";
+        const size_t W = g.clip_dim, P = g.clip_patch, NT = (size_t)(g.clip_image_size / g.clip_patch) * (g.clip_image_size / g.clip_patch) + 1;
+        c->clip_kpad = (int)((3 * P * P + 15) / 16 * 16);
+        add(p + ".embeddings.class_embedding", &c->clip_cls, W);
+        add(p + ".embeddings.patch_embedding.weight", &c->clip_patch_w, W * 3 * P * P);   // stored zero-padded to clip_kpad columns
+        add(p + ".embeddings.position_embedding.weight", &c->clip_pos, NT * W);
+        add(p + ".pre_layrnorm.weight", &c->clip_prew, W);
+        add(p + ".pre_layrnorm.bias", &c->clip_preb, W);
+        for (int i = 0; i < g.clip_layers; ++i) {
+            ClipLayerW& L = c->clip[i];
+            const std::string q = p + ".encoder.layers." + std::to_string(i);
+            lin(q + ".self_attn.q_proj", &L.qw, &L.qb, W, W);
+            lin(q + ".self_attn.k_proj", &L.kw, &L.kb, W, W);
+            lin(q + ".self_attn.v_proj", &L.vw, &L.vb, W, W);
+            lin(q + ".self_attn.out_proj", &L.ow, &L.ob, W, W);
+            add(q + ".layer_norm1.weight", &L.ln1w, W); add(q + ".layer_norm1.bias", &L.ln1b, W);
+            add(q + ".layer_norm2.weight", &L.ln2w, W); add(q + ".layer_norm2.bias", &L.ln2b, W);
+            lin(q + ".mlp.fc1", &L.f1w, &L.f1b, g.clip_mlp_dim, W);
+            lin(q + ".mlp.fc2", &L.f2w, &L.f2b, W, g.clip_mlp_dim);
+        }
+    }
     for (int i = 0; i < g.num_layers; ++i) {
         DitLayerW& L = c->layers[i];
         const std::string p = "dit.layers." + std::to_string(i);
@@ -70,6 +102,12 @@ extern "C" int er_dit_create(const er_dit_config* cfg, int device, er_dit_ctx** 
     c->cfg = *cfg;
     c->device = device;
     c->layers.resize(cfg->num_layers);
+    if (cfg->clip_layers > 0) {
+        if (cfg->clip_dim != 1280 || cfg->clip_heads <= 0 || cfg->clip_dim % cfg->clip_heads || (cfg->clip_dim / cfg->clip_heads) % 16 ||
+            cfg->clip_mlp_dim % 16 || cfg->clip_patch <= 0 || cfg->clip_image_size % cfg->clip_patch)
+            return fail(ER_ERR_UNSUPPORTED, "CLIP encoder shape not built (width 1280, head_dim and mlp multiples of 16)");
+        c->clip.resize(cfg->clip_layers);
+    }
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     dit_register(c);
     *out = c;
@@ -81,6 +119,8 @@ extern "C" int er_dit_destroy(er_dit_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (void* p : c->owned) hipFree(p);
+    for (Buf* b : {&c->cpx, &c->ccol, &c->cpatch, &c->cx, &c->ch, &c->cq, &c->ck, &c->cv, &c->catt, &c->cf})
+        if (b->p) hipFree(b->p);
     for (Buf* b : {&c->x, &c->qkv, &c->att, &c->q2, &c->kv2, &c->u, &c->g, &c->sc, &c->tin, &c->temb0, &c->temb1, &c->temb,
                    &c->tsil, &c->tada, &c->gate, &c->t_dev, &c->xin, &c->pred, &c->czero, &c->ctmp})
         if (b->p) hipFree(b->p);
@@ -93,7 +133,10 @@ extern "C" int er_dit_load_tensor(er_dit_ctx* c, const char* key, const void* da
                                   int on_device) {
     if (!c || !key || !data || ndim < 1 || ndim > 4) return fail(ER_ERR_INVALID, "er_dit_load_tensor: bad argument");
     HIPCHK(hipSetDevice(c->device));
-    auto it = c->slots.find(key);
+    std::string k(key);
+    if (k.rfind("image_encoder.", 0) == 0 && k.find("image_encoder.vision_model.") != 0)
+        k = "image_encoder.vision_model." + k.substr(strlen("image_encoder."));      // transformers >= 5 drops the prefix
+    auto it = c->slots.find(k);
     if (it == c->slots.end()) return 1;
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
@@ -101,6 +144,13 @@ extern "C" int er_dit_load_tensor(er_dit_ctx* c, const char* key, const void* da
     int err = 0;
     std::vector<float> h = to_f32_host(data, dtype, n, on_device, &err);
     if (err) return fail(ER_ERR_HIP, "er_dit_load_tensor(%s): device read failed", key);
+    if (k == "image_encoder.vision_model.embeddings.patch_embedding.weight") {   // [W][3*P*P] -> zero-padded [W][kpad]
+        const size_t W = c->cfg.clip_dim, kin = n / W, kp = c->clip_kpad;
+        std::vector<float> padded(W * kp, 0.f);
+        for (size_t r = 0; r < W; ++r) memcpy(&padded[r * kp], &h[r * kin], kin * 4);
+        h.swap(padded);
+        n = W * kp;
+    }
     if (!*it->second.p) {
         HIPCHK(hipMalloc(it->second.p, n * 4));
         c->owned.push_back(*it->second.p);
@@ -126,6 +176,57 @@ extern "C" int er_dit_project_cond(er_dit_ctx* c, const float* clip_hidden, int 
     ERCHK(ensure(c->ctmp, (size_t)B * M * C));
     HIPRET(linear(clip_hidden, c->cfg.clip_dim, c->projc_w, c->projc_b, c->ctmp.p, C, B * M, C, c->cfg.clip_dim, false, nullptr, 0, st));
     HIPRET(launch_layernorm(c->ctmp.p, c->normc_w, c->normc_b, cond_out, B * M, C, C, C, 1e-5f, st));
+    return ER_OK;
+}
+
+extern "C" int er_dit_encode_image(er_dit_ctx* c, const float* images, int B, int Himg, int Wimg, float* out, void* stream) {
+    if (!c || !images || !out || B <= 0 || Himg <= 0 || Wimg <= 0) return fail(ER_ERR_INVALID, "er_dit_encode_image: bad argument");
+    if (c->cfg.clip_layers <= 0) return fail(ER_ERR_UNSUPPORTED, "this context was created without the image encoder (clip_layers = 0)");
+    ERCHK(er_dit_finalize_weights(c));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    const er_dit_config& g = c->cfg;
+    const int W = g.clip_dim, S = g.clip_image_size, P = g.clip_patch, G = S / P, NP = G * G, NT = NP + 1, H = g.clip_heads,
+              D = W / H, F = g.clip_mlp_dim, R = B * NT, ldS = (NT + 15) / 16 * 16;
+    ERCHK(ensure(c->cpx, (size_t)B * 3 * S * S));
+    ERCHK(ensure(c->ccol, (size_t)B * NP * c->clip_kpad));
+    ERCHK(ensure(c->cpatch, (size_t)B * NP * W));
+    ERCHK(ensure(c->cx, (size_t)R * W));
+    ERCHK(ensure(c->ch, (size_t)R * W));
+    ERCHK(ensure(c->cq, (size_t)R * W));
+    ERCHK(ensure(c->ck, (size_t)R * W));
+    ERCHK(ensure(c->cv, (size_t)R * W));
+    ERCHK(ensure(c->catt, (size_t)R * W));
+    ERCHK(ensure(c->cf, (size_t)R * F));
+    ERCHK(ensure(c->sc, (size_t)H * NT * ldS));
+    auto blocks = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
+    hipLaunchKernelGGL(clip_preprocess_kernel, blocks((long long)B * 3 * S * S), dim3(256), 0, st, images, c->cpx.p, B, Himg, Wimg, S);
+    HIPRET(hipGetLastError());
+    hipLaunchKernelGGL(clip_im2col_kernel, blocks((long long)B * NP * c->clip_kpad), dim3(256), 0, st, c->cpx.p, c->ccol.p, B, S, P, c->clip_kpad);
+    HIPRET(hipGetLastError());
+    HIPRET(linear(c->ccol.p, c->clip_kpad, c->clip_patch_w, nullptr, c->cpatch.p, W, B * NP, W, c->clip_kpad, false, nullptr, 0, st));
+    float* x = c->cx.p;
+    hipLaunchKernelGGL(clip_assemble_kernel, blocks((long long)R * W), dim3(256), 0, st, c->cpatch.p, c->clip_cls, c->clip_pos, x, B, NP, W);
+    HIPRET(hipGetLastError());
+    HIPRET(launch_layernorm(x, c->clip_prew, c->clip_preb, x, R, W, W, W, 1e-5f, st));
+    for (int l = 0; l < g.clip_layers; ++l) {           // CLIPEncoderLayer: pre-LN attention + pre-LN MLP, both residual
+        const ClipLayerW& L = c->clip[l];
+        HIPRET(launch_layernorm(x, L.ln1w, L.ln1b, c->ch.p, R, W, W, W, 1e-5f, st));
+        HIPRET(linear(c->ch.p, W, L.qw, L.qb, c->cq.p, W, R, W, W, false, nullptr, 0, st));
+        HIPRET(linear(c->ch.p, W, L.kw, L.kb, c->ck.p, W, R, W, W, false, nullptr, 0, st));
+        HIPRET(linear(c->ch.p, W, L.vw, L.vb, c->cv.p, W, R, W, W, false, nullptr, 0, st));
+        for (int b = 0; b < B; ++b) {
+            const size_t o = (size_t)b * NT * W;
+            ERCHK(attention_full(c->cq.p + o, W, c->ck.p + o, W, D, c->cv.p + o, W, D, c->catt.p + o, W, c->sc.p, H, D, NT, NT, false, st));
+        }
+        HIPRET(linear(c->catt.p, W, L.ow, L.ob, x, W, R, W, W, false, x, W, st));
+        HIPRET(launch_layernorm(x, L.ln2w, L.ln2b, c->ch.p, R, W, W, W, 1e-5f, st));
+        HIPRET(linear(c->ch.p, W, L.f1w, L.f1b, c->cf.p, F, R, F, W, false, nullptr, 0, st));
+        hipLaunchKernelGGL(gelu_kernel, blocks((long long)R * F), dim3(256), 0, st, c->cf.p, c->cf.p, (long long)R * F);
+        HIPRET(hipGetLastError());
+        HIPRET(linear(c->cf.p, F, L.f2w, L.f2b, x, W, R, W, F, false, x, W, st));
+    }
+    HIPCHK(hipMemcpyAsync(out, x, (size_t)R * W * 4, hipMemcpyDeviceToDevice, st));
     return ER_OK;
 }
 

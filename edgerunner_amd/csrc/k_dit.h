@@ -79,3 +79,64 @@ __global__ void ddim_cfg_step_kernel(float* latents, const float* pred, long lon
 }
 
 }  // namespace er
+
+// ---------------------------------------------------------------------------------------------------
+// CLIP ViT image encoder front (core/models_dit.py:104-111 -> HF CLIPVisionModel)
+namespace er {
+
+// TF.normalize(mean, std) then F.interpolate(bilinear, align_corners=False) to OUT x OUT   (models_dit.py:108-109)
+__global__ void clip_preprocess_kernel(const float* img, float* out, int B, int H, int W, int OUT) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * 3 * OUT * OUT;
+    if (i >= total) return;
+    const int ox = (int)(i % OUT), oy = (int)((i / OUT) % OUT), c = (int)((i / ((long long)OUT * OUT)) % 3);
+    const long long b = i / ((long long)3 * OUT * OUT);
+    const float mean = c == 0 ? 0.48145466f : (c == 1 ? 0.4578275f : 0.40821073f);
+    const float stdv = c == 0 ? 0.26862954f : (c == 1 ? 0.26130258f : 0.27577711f);
+    const float sy = fmaxf(((float)oy + 0.5f) * ((float)H / (float)OUT) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)ox + 0.5f) * ((float)W / (float)OUT) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float* p = img + (b * 3 + c) * (long long)H * W;
+    const float v00 = (p[(long long)y0 * W + x0] - mean) / stdv, v01 = (p[(long long)y0 * W + x1] - mean) / stdv;
+    const float v10 = (p[(long long)y1 * W + x0] - mean) / stdv, v11 = (p[(long long)y1 * W + x1] - mean) / stdv;
+    out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+// Conv2d(3, width, kernel P, stride P, no bias) as a GEMM: A[b*G*G + py*G + px][c*P*P + ky*P + kx] (zero-padded to lda)
+__global__ void clip_im2col_kernel(const float* px, float* A, int B, int S, int P, int lda) {
+    const int G = S / P;
+    const long long total = (long long)B * G * G * lda;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int col = (int)(i % lda);
+    const long long row = i / lda;
+    const int gx = (int)(row % G), gy = (int)((row / G) % G);
+    const long long b = row / ((long long)G * G);
+    float v = 0.f;
+    if (col < 3 * P * P) {
+        const int c = col / (P * P), r = col - c * P * P, ky = r / P, kx = r - ky * P;
+        v = px[((b * 3 + c) * S + (gy * P + ky)) * (long long)S + gx * P + kx];
+    }
+    A[i] = v;
+}
+
+// x[b][0] = class_embedding + pos[0]; x[b][1+p] = patches[b][p] + pos[1+p]     (CLIPVisionEmbeddings.forward)
+__global__ void clip_assemble_kernel(const float* patches, const float* cls, const float* pos, float* x, int B, int NP, int C) {
+    const long long total = (long long)B * (NP + 1) * C;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int tkn = (int)((i / C) % (NP + 1));
+    const long long b = i / ((long long)(NP + 1) * C);
+    const float base = tkn == 0 ? cls[c] : patches[(b * NP + (tkn - 1)) * C + c];
+    x[i] = base + pos[(long long)tkn * C + c];
+}
+
+__global__ void gelu_kernel(const float* x, float* y, long long n) {       // exact (erf) GELU, in place allowed
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+}
+
+}  // namespace er

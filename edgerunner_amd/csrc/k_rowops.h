@@ -41,6 +41,7 @@ inline hipError_t launch_layernorm(const float* x, const float* w, const float* 
     if (rows == 0) return hipSuccess;
     switch (cols) {
         case 1536: hipLaunchKernelGGL((layernorm_rows_kernel<24>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
+        case 1280: hipLaunchKernelGGL((layernorm_rows_kernel<20>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
         case 1024: hipLaunchKernelGGL((layernorm_rows_kernel<16>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
         case 512:  hipLaunchKernelGGL((layernorm_rows_kernel<8>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;
         case 256:  hipLaunchKernelGGL((layernorm_rows_kernel<4>), dim3(grid), dim3(ER_WG), 0, st, x, w, b, y, rows, ldx, ldy, eps); break;

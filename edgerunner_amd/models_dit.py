@@ -3,10 +3,10 @@ MI355X: projected image condition -> DiT denoiser (core/transformer/dit.py) samp
 classifier-free guidance -> latents ``[B, 2048, 64]`` that ``LMM.generate`` consumes in
 ``cond_mode='point_latent'`` (infer_dit.py:55,111-113).
 
-Built: ``proj_cond``/``norm_cond`` (get_cond after the image encoder), ``DiT.forward``, ``run`` (latents=None).
-Not built: the CLIP ViT-H/14 image encoder itself (``image_encoder.*``; frozen third-party model whose
-weights cannot be fetched here) - ``get_cond`` therefore takes the encoder's ``last_hidden_state``
-``[B, 257, 1280]``; training ``forward`` and the img2img branch (``latents`` given) are out of scope.
+Built: the CLIP ViT-H/14 image encoder (``image_encoder.vision_model.*``; architecture only - its pretrained
+weights cannot be fetched here, so parity runs use synthetic weights), ``proj_cond``/``norm_cond``,
+``DiT.forward``, ``run`` (latents=None).  Out of scope: training ``forward``, the img2img branch (``latents`` given),
+background removal / recentering of the input photo (rembg, kiui: infer_dit.py:83-96).
 """
 from __future__ import annotations
 
@@ -21,14 +21,18 @@ CLIP_DIM = 1280   # laion/CLIP-ViT-H-14 hidden width (core/models_dit.py:56)
 
 
 class MDiT:
-    def __init__(self, opt, device="cuda:0"):
+    def __init__(self, opt, device="cuda:0", clip_layers: int = 32):
+        """clip_layers: depth of the CLIP ViT image encoder to expect in the checkpoint (32 = ViT-H/14 as in the
+        reference; 0 = no image encoder: get_cond then takes its last_hidden_state directly)."""
         self.opt = opt
+        self.clip_layers = clip_layers
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise native.NativeError("MDiT needs a HIP device; there is no CPU fallback")
         self.lib = native.load_library()
         cfg = native.ErDitConfig(hidden_dim=opt.dit_hidden_dim, num_heads=opt.dit_num_heads, num_layers=opt.dit_num_layers,
-                                 latent_size=opt.point_latent_size, latent_dim=opt.point_latent_dim, clip_dim=CLIP_DIM)
+                                 latent_size=opt.point_latent_size, latent_dim=opt.point_latent_dim, clip_dim=CLIP_DIM,
+                                 clip_layers=clip_layers, clip_heads=16, clip_mlp_dim=5120, clip_image_size=224, clip_patch=14)
         self._ctx = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         native.check(self.lib.er_dit_create(C.byref(cfg), idx, C.byref(self._ctx)), "er_dit_create")
@@ -83,10 +87,21 @@ class MDiT:
 
     @torch.no_grad()
     def get_cond(self, inputs: torch.Tensor) -> torch.Tensor:
-        """core/models_dit.py:104-115 from the image encoder's last_hidden_state [B, 257, 1280]."""
+        """core/models_dit.py:104-115.  inputs: images [B, 3, H, W] in [0, 1] (normalised, resized to 224 and
+        encoded by the CLIP ViT here) or an already computed last_hidden_state [B, 257, 1280]."""
+        if inputs.dim() == 4:
+            if self.clip_layers <= 0:
+                raise NotImplementedError("this MDiT was created without the image encoder (clip_layers=0)")
+            img = inputs.to(self.device, torch.float32).contiguous()
+            self._sync_in()
+            with torch.cuda.stream(self.stream):
+                hid = torch.empty((img.shape[0], 257, CLIP_DIM), dtype=torch.float32, device=self.device)
+                native.check(self.lib.er_dit_encode_image(self._ctx, native.ptr(img), img.shape[0], img.shape[2], img.shape[3],
+                                                          native.ptr(hid), self._sp()), "er_dit_encode_image")
+            self._sync_out()
+            inputs = hid
         if inputs.dim() != 3 or inputs.shape[-1] != CLIP_DIM:
-            raise NotImplementedError("the CLIP ViT-H/14 image encoder is not built: pass its last_hidden_state "
-                                      f"[B, 257, {CLIP_DIM}] (got {tuple(inputs.shape)})")
+            raise ValueError(f"expected images [B,3,H,W] or CLIP hidden states [B,257,{CLIP_DIM}], got {tuple(inputs.shape)}")
         x = inputs.to(self.device, torch.float32).contiguous()
         self._sync_in()
         with torch.cuda.stream(self.stream):

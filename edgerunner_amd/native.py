@@ -25,7 +25,8 @@ EXPORTS = [
     "er_abi_version", "er_last_error", "er_create", "er_destroy", "er_load_tensor", "er_finalize_weights",
     "er_kv_reserve", "er_encode_cond", "er_embed_tokens", "er_prefill", "er_logits", "er_feed", "er_decode",
     "er_meto_decode", "er_meto_encode", "er_dit_create", "er_dit_destroy", "er_dit_load_tensor",
-    "er_dit_finalize_weights", "er_dit_project_cond", "er_dit_forward", "er_dit_sample", "er_kernel_kind_name", "er_profile_decode_kernels", "er_last_decode_ms",
+    "er_dit_finalize_weights", "er_dit_project_cond", "er_dit_encode_image", "er_dit_forward", "er_dit_sample",
+    "er_kernel_kind_name", "er_profile_decode_kernels", "er_last_decode_ms",
     "er_k_gemv", "er_k_attn_decode", "er_k_gemm", "er_k_layernorm", "er_k_softmax", "er_k_sample_head",
 ]
 
@@ -39,7 +40,8 @@ class ErConfig(C.Structure):
 
 
 class ErDitConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("hidden_dim", "num_heads", "num_layers", "latent_size", "latent_dim", "clip_dim")]
+    _fields_ = [(n, C.c_int32) for n in ("hidden_dim", "num_heads", "num_layers", "latent_size", "latent_dim", "clip_dim",
+                                         "clip_layers", "clip_heads", "clip_mlp_dim", "clip_image_size", "clip_patch")]
 
 
 class ErDecodeParams(C.Structure):
@@ -91,6 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.er_dit_load_tensor.argtypes = [vp, C.c_char_p, vp, ci, ci, C.POINTER(C.c_int64), ci]
     lib.er_dit_finalize_weights.argtypes = [vp]
     lib.er_dit_project_cond.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.er_dit_encode_image.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     lib.er_dit_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), ci, ci, vp, vp]
     lib.er_dit_sample.argtypes = [vp, vp, ci, ci, vp, ci, cf, vp]
     lib.er_k_gemv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]

@@ -245,3 +245,26 @@ def dit_tensor_specs(opt, clip_dim: int = 1280) -> List[Tuple[str, Tuple[int, ..
 def make_dit_state_dict(opt, seed: int = 0, style: str = "perturbed") -> Dict[str, torch.Tensor]:
     # encoder-style biases (torch default) in both styles: keys do not start with "mesh_decoder"
     return {k: make_tensor("mdit." + k, shape, kind, seed, style) for k, shape, kind in dit_tensor_specs(opt)}
+
+
+def clip_tensor_specs(num_layers: int = 32, width: int = 1280, mlp: int = 5120, patch: int = 14, tokens: int = 257):
+    """image_encoder.* entries (HF CLIPVisionModel, transformers 4.46.2 key names).  Synthetic init only - the
+    pretrained laion/CLIP-ViT-H-14 weights are not available offline."""
+    p = "image_encoder.vision_model"
+    specs = [(f"{p}.embeddings.class_embedding", (width,), "normal:0.03"),
+             (f"{p}.embeddings.patch_embedding.weight", (width, 3, patch, patch), "normal:0.02"),
+             (f"{p}.embeddings.position_embedding.weight", (tokens, width), "normal:0.02"),
+             (f"{p}.pre_layrnorm.weight", (width,), "ln_w"), (f"{p}.pre_layrnorm.bias", (width,), "ln_b")]
+    for i in range(num_layers):
+        L = f"{p}.encoder.layers.{i}"
+        for q in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            specs += [(f"{L}.self_attn.{q}.weight", (width, width), "normal:0.02"), (f"{L}.self_attn.{q}.bias", (width,), f"bias:{width}")]
+        specs += [(f"{L}.layer_norm1.weight", (width,), "ln_w"), (f"{L}.layer_norm1.bias", (width,), "ln_b"),
+                  (f"{L}.mlp.fc1.weight", (mlp, width), "normal:0.02"), (f"{L}.mlp.fc1.bias", (mlp,), f"bias:{width}"),
+                  (f"{L}.mlp.fc2.weight", (width, mlp), "normal:0.02"), (f"{L}.mlp.fc2.bias", (width,), f"bias:{mlp}"),
+                  (f"{L}.layer_norm2.weight", (width,), "ln_w"), (f"{L}.layer_norm2.bias", (width,), "ln_b")]
+    return specs
+
+
+def make_clip_state_dict(num_layers: int = 32, seed: int = 0, style: str = "perturbed") -> Dict[str, torch.Tensor]:
+    return {k: make_tensor("clip." + k, shape, kind, seed, style) for k, shape, kind in clip_tensor_specs(num_layers)}

@@ -160,6 +160,8 @@ typedef struct {
     int32_t hidden_dim, num_heads, num_layers;   /* Options.dit_hidden_dim / dit_num_heads / dit_num_layers */
     int32_t latent_size, latent_dim;             /* point_latent_size (2048), point_latent_dim (64)          */
     int32_t clip_dim;                            /* width of the image encoder's last_hidden_state (1280)   */
+    int32_t clip_layers, clip_heads, clip_mlp_dim; /* CLIP ViT-H/14: 32 / 16 / 5120; clip_layers = 0: encoder not loaded */
+    int32_t clip_image_size, clip_patch;         /* 224 / 14                                                  */
 } er_dit_config;
 typedef struct er_dit_ctx er_dit_ctx;
 int er_dit_create(const er_dit_config* cfg, int device, er_dit_ctx** out);
@@ -172,6 +174,11 @@ int er_dit_finalize_weights(er_dit_ctx* ctx);
  * clip_hidden_dev float[B, M, clip_dim] -> cond_out_dev float[B, M, hidden_dim] */
 int er_dit_project_cond(er_dit_ctx* ctx, const float* clip_hidden_dev, int batch, int m_tokens,
                         float* cond_out_dev, void* stream);
+/* The frozen image encoder of MDiT.get_cond (core/models_dit.py:104-111): normalize + bilinear resize to 224 +
+ * CLIPVisionModel(...).last_hidden_state.  images_dev float[B,3,H,W] in [0,1] -> clip_hidden_out_dev float[B, 257, clip_dim].
+ * Checkpoint keys "image_encoder.vision_model.*" (transformers 4.46.2 names). */
+int er_dit_encode_image(er_dit_ctx* ctx, const float* images_dev, int batch, int height, int width,
+                        float* clip_hidden_out_dev, void* stream);
 /* DiT.forward(x, c, t)   core/transformer/dit.py:168-196: x float[B,N,latent_dim], c float[B,M,hidden], t_host float[B] */
 int er_dit_forward(er_dit_ctx* ctx, const float* x_dev, const float* c_dev, const float* t_host, int batch,
                    int m_tokens, float* out_dev, void* stream);

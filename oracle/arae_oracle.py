@@ -461,3 +461,53 @@ def mdit_run(sd: StateDict, cond, init_latents, num_heads: int, num_inference_st
         pred = u + guidance_scale * (cnd - u)
         latents = ddim_step_v(latents, pred, t, ac, final, ratio)
     return latents
+
+
+# ----------------------------------------------------------------------------- CLIP ViT-H/14 image encoder (f3)
+# MDiT.get_cond (core/models_dit.py:104-115) runs a frozen HuggingFace CLIPVisionModel
+# ('laion/CLIP-ViT-H-14-laion2B-s32B-b79K': 32 layers, width 1280, 16 heads, MLP 5120, gelu, patch 14, 224 px) and
+# takes .last_hidden_state.  The model code is third-party (transformers==4.46.2 models/clip/modeling_clip.py:
+# CLIPVisionEmbeddings / CLIPEncoderLayer / CLIPAttention / CLIPMLP), restated here at state_dict level with the
+# 4.46.2 key names ("image_encoder.vision_model.*"); oracle/make_golden.py checks it against the installed
+# transformers' CLIPVisionModel (random init - the pretrained weights cannot be fetched).
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(images):
+    """core/models_dit.py:108-109: TF.normalize(mean, std) then bilinear resize to 224 (align_corners=False)."""
+    mean = torch.tensor(CLIP_MEAN, dtype=images.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD, dtype=images.dtype).view(1, 3, 1, 1)
+    x = (images - mean) / std
+    return F.interpolate(x, (224, 224), mode="bilinear", align_corners=False)
+
+
+def clip_vision_forward(sd: StateDict, pixel_values, num_heads: int = 16, prefix="image_encoder.vision_model", eps=1e-5):
+    """CLIPVisionTransformer.forward -> last_hidden_state [B, 257, width] (no post_layernorm)."""
+    B = pixel_values.shape[0]
+    w = sd[f"{prefix}.embeddings.patch_embedding.weight"]
+    x = F.conv2d(pixel_values, w, stride=w.shape[-1]).flatten(2).transpose(1, 2)
+    cls = sd[f"{prefix}.embeddings.class_embedding"].expand(B, 1, -1)
+    x = torch.cat([cls, x], dim=1) + sd[f"{prefix}.embeddings.position_embedding.weight"]
+    C = x.shape[-1]
+    D = C // num_heads
+    x = F.layer_norm(x, (C,), sd[f"{prefix}.pre_layrnorm.weight"], sd[f"{prefix}.pre_layrnorm.bias"], eps)
+    i = 0
+    while f"{prefix}.encoder.layers.{i}.mlp.fc1.weight" in sd:
+        L = f"{prefix}.encoder.layers.{i}"
+        h = F.layer_norm(x, (C,), sd[f"{L}.layer_norm1.weight"], sd[f"{L}.layer_norm1.bias"], eps)
+        N = h.shape[1]
+        q = (_lin(sd, f"{L}.self_attn.q_proj", h) * (D ** -0.5)).view(B, N, num_heads, D).transpose(1, 2)
+        k = _lin(sd, f"{L}.self_attn.k_proj", h).view(B, N, num_heads, D).transpose(1, 2)
+        v = _lin(sd, f"{L}.self_attn.v_proj", h).view(B, N, num_heads, D).transpose(1, 2)
+        a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v
+        x = x + _lin(sd, f"{L}.self_attn.out_proj", a.transpose(1, 2).reshape(B, N, C))
+        h = F.layer_norm(x, (C,), sd[f"{L}.layer_norm2.weight"], sd[f"{L}.layer_norm2.bias"], eps)
+        x = x + _lin(sd, f"{L}.mlp.fc2", F.gelu(_lin(sd, f"{L}.mlp.fc1", h)))
+        i += 1
+    return x
+
+
+def mdit_get_cond(sd: StateDict, images, num_heads: int = 16):
+    """MDiT.get_cond (core/models_dit.py:104-115) from images [B,3,H,W] in [0,1]."""
+    return dit_project_cond(sd, clip_vision_forward(sd, clip_preprocess(images), num_heads))

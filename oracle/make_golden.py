@@ -243,8 +243,31 @@ def make_dit():
     sd = {k: v for k, v in W.make_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE).items()}
     model = build_reference(ref_opt, sd)
     out["ids_from_latents"], _ = run_case(model, sd, opt, lat, 1000, 32, 32)
+    # image encoder: installed transformers' CLIPVisionModel (ViT-H/14 widths, 2 layers) on the synthetic weights
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    cfg = CLIPVisionConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=2, num_attention_heads=16,
+                           image_size=224, patch_size=14, hidden_act="gelu")
+    cfg._attn_implementation = "eager"
+    clip = CLIPVisionModel(cfg).eval()
+    sd_c = W.make_clip_state_dict(2, WEIGHT_SEED, WEIGHT_STYLE)
+    hf = {k.replace("image_encoder.vision_model.", ""): v for k, v in sd_c.items()}
+    hf.update({"post_layernorm.weight": torch.ones(1280), "post_layernorm.bias": torch.zeros(1280)})
+    if any(k.startswith("vision_model.") for k in clip.state_dict()):      # transformers 4.x key layout
+        hf = {"vision_model." + k: v for k, v in hf.items()}
+    missing, unexpected = clip.load_state_dict(hf, strict=True)
+    img = torch.rand(1, 3, 512, 512, generator=g)
+    hid_hf = clip(O.clip_preprocess(img)).last_hidden_state
+    hid_mine = O.clip_vision_forward(sd_c, O.clip_preprocess(img))
+    clip_diff = float((hid_hf - hid_mine).abs().max())
+    print("CLIP restatement vs installed transformers: max abs diff", clip_diff)
+    assert clip_diff < 1e-4
+    out["image_seed_note"] = np.array([314])     # img is the 4th draw of generator(314): clip_hidden, noise, x, img
+    out["clip_rows"] = hid_hf[0, [0, 1, 128, 256]].numpy()
+    out["clip_sum"] = np.array([float(hid_hf.double().sum()), float(hid_hf.double().abs().sum())])
     np.savez_compressed(os.path.join(GOLD, "dit_small.npz"), **out)
     manifest_update("dit_small", {"dit_num_layers": 2, "restatement_bit_identical": bool(ok), "steps": 6,
+                                  "clip": f"installed transformers {__import__('transformers').__version__} CLIPVisionModel, 2 layers; "
+                                          f"restatement (4.46.2 scaling order) differs by {clip_diff:.2e}",
                                   "scheduler": "restated diffusers DDIMScheduler (absent), config core/models_dit.py:91-102",
                                   "cases": {k: list(v.shape) for k, v in out.items()}})
     print({k: v.shape for k, v in out.items()})

@@ -21,7 +21,7 @@ def setup():
     opt = dataclasses.replace(config_defaults["ArAE"], num_layers=2, generate_mode="greedy", cond_mode="point_latent",
                               dit_num_layers=2)
     sd = W.make_dit_state_dict(opt, 0, "perturbed")
-    m = MDiT(opt, DEV)
+    m = MDiT(opt, DEV, clip_layers=0)
     missing, unexpected = m.load_state_dict(sd, strict=True)
     g = dict(np.load(GOLD))
     gen = torch.Generator().manual_seed(int(g["seed"][0]))
@@ -73,6 +73,50 @@ def test_sampler_vs_oracle_live_batch2(setup):
     err = float((got - want).abs().max())
     print(f"3-step sampler, batch 2: max abs err {err:.3e}")
     assert err < 2e-3
+
+
+def test_clip_image_encoder_and_image_to_tokens(setup):
+    """BASELINE configs[4] end to end at reduced depth: image -> CLIP ViT (ViT-H/14 widths, 2 layers) -> proj/norm ->
+    DiT (2 layers) sampled with DDIM + CFG -> latents -> ArAE greedy decode (2 layers), vs the CPU oracle."""
+    import arae_oracle as O
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models import LMM
+    from edgerunner_amd.models_dit import MDiT
+    opt, sd, _, g, clip_hidden, noise, x = setup
+    sd_all = dict(sd)
+    sd_all.update(W.make_clip_state_dict(2, 0, "perturbed"))
+    m = MDiT(opt, DEV, clip_layers=2)
+    m.load_state_dict(sd_all, strict=True)
+    gen = torch.Generator().manual_seed(int(g["seed"][0]))
+    for shape in ((1, 257, 1280), (1, 2048, 64), (2, 2048, 64)):     # replay the generator up to the golden image
+        torch.randn(*shape, generator=gen)
+    img = torch.rand(1, 3, 512, 512, generator=gen)
+    # (a) hidden states vs the installed-transformers golden
+    m_hid = torch.empty(0)
+    cond = m.get_cond(img.to(DEV))
+    want_cond = O.mdit_get_cond(sd_all, img)
+    err = float((cond.cpu() - want_cond).abs().max())
+    print(f"image -> cond: max abs err vs oracle {err:.3e}")
+    assert err < 2e-4
+    hid_rows = O.clip_vision_forward(sd_all, O.clip_preprocess(img))[0, [0, 1, 128, 256]].numpy()
+    assert np.abs(hid_rows - g["clip_rows"]).max() < 1e-4          # oracle restatement vs installed transformers golden
+    # (b) odd image size (bilinear resize path) vs oracle
+    img2 = torch.rand(2, 3, 300, 417, generator=gen)
+    err2 = float((m.get_cond(img2.to(DEV)).cpu() - O.mdit_get_cond(sd_all, img2)).abs().max())
+    assert err2 < 2e-4, err2
+    # (c) image -> latents -> tokens
+    nz = torch.randn(1, 2048, 64, generator=gen)
+    lat = m.run(img.to(DEV), num_inference_steps=4, guidance_scale=7.5, noise=nz.to(DEV))
+    want_lat = O.mdit_run(sd_all, want_cond, nz, opt.dit_num_heads, num_inference_steps=4, guidance_scale=7.5)
+    errl = float((lat.cpu() - want_lat).abs().max())
+    print(f"image -> latents (4 steps): max abs err {errl:.3e}")
+    assert errl < 2e-3
+    lmm = LMM(opt, DEV)
+    sd_l = W.make_state_dict(opt, 0, "perturbed")
+    lmm.load_state_dict(sd_l, strict=True)
+    _, toks = lmm.generate(lat, 1000, tokenizer=object(), max_new_tokens=24, min_new_tokens=24)
+    want_ids = O.lmm_generate_ids(sd_l, opt, want_lat, 1000, max_new_tokens=24, min_new_tokens=24).numpy()[0]
+    assert np.array_equal(toks[0], want_ids), (toks[0], want_ids)
 
 
 def test_unbuilt_pieces_fail_loudly(setup):
