@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's ``infer_dit.py`` (image -> mesh tokens) on MI355X.
+
+    python infer_dit.py DiT --workspace out --resume lmm.safetensors --resume2 mdit.safetensors --test_path images/
+
+Pipeline (reference infer_dit.py:40-140): image -> MDiT.run (CLIP ViT-H/14 -> DiT, 100 DDIM steps, CFG 7.5) ->
+latents [1,2048,64] -> LMM.generate in cond_mode 'point_latent' -> ``{name}_{i}_{n}f_tokens.npy`` (+ .ply).
+Inputs: RGBA / RGB images readable by PIL, or .npy arrays [H,W,3|4] in [0,1].  Background removal and
+recentering (rembg / kiui in the reference) are not reproduced: supply a segmented, centred image.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from edgerunner_amd import dist as D  # noqa: E402
+from edgerunner_amd import meshio  # noqa: E402
+from edgerunner_amd.meto import get_tokenizer  # noqa: E402
+from edgerunner_amd.models import LMM  # noqa: E402
+from edgerunner_amd.models_dit import MDiT  # noqa: E402
+from edgerunner_amd.options import parse_cli  # noqa: E402
+from edgerunner_amd.utils import seed_everything, trim_tokens  # noqa: E402
+
+
+def load_ckpt(path):
+    if path.endswith("safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path, device="cpu")
+    return torch.load(path, map_location="cpu")
+
+
+def load_image(path):
+    if path.endswith(".npy"):
+        a = np.load(path).astype(np.float32)
+    else:
+        from PIL import Image
+        a = np.asarray(Image.open(path)).astype(np.float32) / 255.0
+    if a.ndim == 2:
+        a = np.repeat(a[..., None], 3, axis=-1)
+    if a.shape[-1] == 4:                      # composite on white (infer_dit.py:93)
+        a = a[..., :3] * a[..., 3:4] + (1 - a[..., 3:4])
+    return a[..., :3]
+
+
+def main(argv=None):
+    opt = parse_cli(argv)
+    rank, world, local = D.init_process_group()
+    seed_everything(opt.seed)
+    if not torch.cuda.is_available():
+        raise SystemExit("no HIP device visible: this path has no CPU fallback")
+    device = torch.device("cuda", local)
+    opt.cond_mode = "point_latent"            # infer_dit.py:55
+    precision = os.environ.get("EDGERUNNER_PRECISION", "fp16")
+    model = LMM(opt, device, precision=precision)
+    model_dit = MDiT(opt, device)
+    from edgerunner_amd import weights as W
+    if opt.resume is not None:
+        model.load_state_dict(load_ckpt(opt.resume), strict=False)
+    else:
+        print("[WARN] model randomly initialized, are you sane?")
+        model.mesh_decoder.load_state_iter(W.iter_state_dict(opt, opt.seed, "reference"), strict=True)
+    if opt.resume2 is not None:
+        model_dit.load_state_dict(load_ckpt(opt.resume2), strict=False)
+    else:
+        sd = W.make_dit_state_dict(opt, opt.seed, "reference")
+        sd.update(W.make_clip_state_dict(32, opt.seed, "reference"))
+        model_dit.load_state_dict(sd, strict=True)
+    tokenizer, _ = get_tokenizer(opt)
+
+    assert opt.test_path is not None
+    paths = sorted(glob.glob(os.path.join(opt.test_path, "*"))) if os.path.isdir(opt.test_path) else [opt.test_path]
+    os.makedirs(opt.workspace, exist_ok=True)
+    jobs = [(p, i, nf) for p in paths for i in range(opt.test_repeat) for nf in opt.test_num_face]
+    for j in D.shard_indices(len(jobs), rank, world):
+        path, i, num_faces = jobs[j]
+        name = os.path.splitext(os.path.basename(path))[0]
+        image = torch.from_numpy(load_image(path)).permute(2, 0, 1).contiguous().unsqueeze(0).float().to(device)
+        cond = F.interpolate(image, (512, 512), mode="bilinear", align_corners=False)      # infer_dit.py:97
+        t0 = time.time()
+        latents = model_dit.run(cond)
+        meshes, tokens = model.generate(latents, num_faces=num_faces, max_new_tokens=opt.test_max_seq_length,
+                                        tokenizer=tokenizer, clean=True, seed=opt.seed + 7919 * j)
+        tokens = trim_tokens(tokens[0])
+        filename = f"{name}_{i}" + (f"_{num_faces}f" if opt.use_num_face_cond else "")
+        np.save(f"{opt.workspace}/{filename}_tokens.npy", tokens)
+        if meshes[0] is not None:
+            meshio.save_ply(f"{opt.workspace}/{filename}.ply", meshes[0][0], meshes[0][1])
+        torch.cuda.synchronize()
+        print(f"[INFO] Processing {path} --> {filename}, {len(tokens)} tokens, time = {time.time() - t0:.4f}s")
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()
