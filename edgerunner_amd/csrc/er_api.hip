@@ -689,9 +689,7 @@ static int attention_full(const float* Q, int ldq, const float* Kp, int ldk, lon
     g.Z2 = H; g.M = N; g.N = M; g.K = D; g.div = sqrtf((float)D);
     g.causal = causal ? 1 : 0; g.causal_off = M - N;
     HIPRET(launch_gemm(g, H, st));
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(N, H), dim3(ER_WG), 0, st, sc, N, M, (long long)ldS, ldS,
-                       (long long)N * ldS, causal ? 1 : 0, M - N);
-    HIPRET(hipGetLastError());
+    HIPRET(launch_softmax_rows(sc, N, M, (long long)ldS, ldS, (long long)N * ldS, H, causal ? 1 : 0, M - N, st));
     GemmArgs p = gemm_args_default();
     p.A = sc; p.lda = ldS; p.sA2 = (long long)N * ldS;
     p.B = Vp; p.ldb = ldv; p.sB2 = v_hstride; p.b_is_kn = 1; p.kb_valid = M;
@@ -1151,15 +1149,23 @@ extern "C" int er_k_gemm(const float* a, const float* b, const float* bias, cons
     return ER_OK;
 }
 
+extern "C" int er_k_gemm_f16(const float* a, const void* w, const float* bias, const float* resid, float* cc, int m, int n, int k,
+                             int lda, int ldb, int ldc, int relu, void* stream) {
+    if (k % 32) return fail(ER_ERR_INVALID, "er_k_gemm_f16: k must be a multiple of 32");
+    GemmArgs g = gemm_args_default();
+    g.A = a; g.B = reinterpret_cast<const float*>(w); g.C = cc; g.bias = bias; g.resid = resid; g.M = m; g.N = n; g.K = k;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.relu = relu;
+    HIPRET(launch_gemm_f16(g, (hipStream_t)stream));
+    return ER_OK;
+}
+
 extern "C" int er_k_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int cols, float eps, void* stream) {
     HIPRET(launch_layernorm(x, w, b, y, rows, cols, cols, cols, eps, (hipStream_t)stream));
     return ER_OK;
 }
 
 extern "C" int er_k_softmax(float* s, int rows, int cols, int ld, int causal, void* stream) {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows, 1), dim3(ER_WG), 0, (hipStream_t)stream, s, rows, cols, (long long)ld, ld,
-                       0LL, causal, 0);
-    HIPRET(hipGetLastError());
+    HIPRET(launch_softmax_rows(s, rows, cols, (long long)ld, ld, 0LL, 1, causal, 0, (hipStream_t)stream));
     return ER_OK;
 }
 

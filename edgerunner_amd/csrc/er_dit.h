@@ -1,5 +1,5 @@
 // DiT image-conditioned front-end behind the C ABI (er_dit_*): included at the end of er_api.hip so it can
-// reuse the prefill building blocks (linear(), attention_full(), ensure(), fail(), HIPCHK/HIPRET/ERCHK).
+// reuse the prefill building blocks (the GEMM launchers, attention_full, ensure, fail, HIPCHK/HIPRET/ERCHK).
 // Reference: core/transformer/dit.py (DiT, DiTLayer, TimestepEmbedding) and core/models_dit.py::MDiT.run.
 #pragma once
 #include "k_dit.h"
@@ -34,6 +34,8 @@ struct er_dit_ctx {
     Buf cpx, ccol, cpatch, cx, ch, cq, ck, cv, catt, cf;
     std::map<std::string, DitSlot> slots;
     std::vector<void*> owned;
+    bool fast = false;                                   // fp16-input MFMA for every Linear (weights stored fp16 too)
+    std::map<const float*, const _Float16*> half_of;     // fp32 weight block -> its fp16 copy
     Buf x, qkv, att, q2, kv2, u, g, sc, tin, temb0, temb1, temb, tsil, tada, gate, t_dev, xin, pred, czero, ctmp;
 };
 
@@ -58,7 +60,7 @@ static void dit_register(er_dit_ctx* c) {
     if (g.clip_layers > 0) {
         const std::string p = "image_encoder.vision_model";
         const size_t W = g.clip_dim, P = g.clip_patch, NT = (size_t)(g.clip_image_size / g.clip_patch) * (g.clip_image_size / g.clip_patch) + 1;
-        c->clip_kpad = (int)((3 * P * P + 15) / 16 * 16);
+        c->clip_kpad = (int)((3 * P * P + 31) / 32 * 32);
         add(p + ".embeddings.class_embedding", &c->clip_cls, W);
         add(p + ".embeddings.patch_embedding.weight", &c->clip_patch_w, W * 3 * P * P);   // stored zero-padded to clip_kpad columns
         add(p + ".embeddings.position_embedding.weight", &c->clip_pos, NT * W);
@@ -102,6 +104,8 @@ extern "C" int er_dit_create(const er_dit_config* cfg, int device, er_dit_ctx** 
     c->cfg = *cfg;
     c->device = device;
     c->layers.resize(cfg->num_layers);
+    if (cfg->weight_dtype != ER_F32 && cfg->weight_dtype != ER_F16) return fail(ER_ERR_UNSUPPORTED, "DiT weight_dtype must be fp32 or fp16");
+    c->fast = cfg->weight_dtype == ER_F16;
     if (cfg->clip_layers > 0) {
         if (cfg->clip_dim != 1280 || cfg->clip_heads <= 0 || cfg->clip_dim % cfg->clip_heads || (cfg->clip_dim / cfg->clip_heads) % 16 ||
             cfg->clip_mlp_dim % 16 || cfg->clip_patch <= 0 || cfg->clip_image_size % cfg->clip_patch)
@@ -155,6 +159,17 @@ extern "C" int er_dit_load_tensor(er_dit_ctx* c, const char* key, const void* da
         HIPCHK(hipMalloc(it->second.p, n * 4));
         c->owned.push_back(*it->second.p);
     }
+    const bool is_matrix = k.size() > 7 && k.compare(k.size() - 7, 7, ".weight") == 0 && (ndim >= 2) &&
+                           k.find("position_embedding") == std::string::npos;     // GEMM operands only, not lookup tables
+    if (c->fast && is_matrix) {          // Linear / patch-conv weights: fp16 copy for the MFMA path, fp32 copy holds the same rounded values
+        std::vector<_Float16> hh(n);
+        for (size_t i = 0; i < n; ++i) { hh[i] = (_Float16)h[i]; h[i] = (float)hh[i]; }
+        _Float16* dh = nullptr;
+        HIPCHK(hipMalloc((void**)&dh, n * 2));
+        c->owned.push_back(dh);
+        HIPCHK(hipMemcpy(dh, hh.data(), n * 2, hipMemcpyHostToDevice));
+        c->half_of[*it->second.p] = dh;
+    }
     HIPCHK(hipMemcpy(*it->second.p, h.data(), n * 4, hipMemcpyHostToDevice));
     it->second.loaded = true;
     return ER_OK;
@@ -167,6 +182,22 @@ extern "C" int er_dit_finalize_weights(er_dit_ctx* c) {
     return ER_OK;
 }
 
+// Linear layer: fp32 MFMA, or (fast mode) fp16-input MFMA with the activation rounded to fp16 on the way in
+static hipError_t dlin(er_dit_ctx* c, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N,
+                       int K, const float* resid, int ldr, const float* gate, int gate_rows, hipStream_t st) {
+    GemmArgs g = gemm_args_default();
+    g.A = A; g.B = W; g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldr;
+    g.gate = gate; g.gate_rows = gate_rows; g.gate_bstride = N;
+    if (c->fast && K % 32 == 0) {
+        auto it = c->half_of.find(W);
+        if (it != c->half_of.end()) {
+            g.B = reinterpret_cast<const float*>(it->second);
+            return launch_gemm_f16(g, st);
+        }
+    }
+    return launch_gemm(g, 1, st);
+}
+
 extern "C" int er_dit_project_cond(er_dit_ctx* c, const float* clip_hidden, int B, int M, float* cond_out, void* stream) {
     if (!c || !clip_hidden || !cond_out || B <= 0 || M <= 0) return fail(ER_ERR_INVALID, "er_dit_project_cond: bad argument");
     ERCHK(er_dit_finalize_weights(c));
@@ -174,7 +205,7 @@ extern "C" int er_dit_project_cond(er_dit_ctx* c, const float* clip_hidden, int 
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     const int C = c->cfg.hidden_dim;
     ERCHK(ensure(c->ctmp, (size_t)B * M * C));
-    HIPRET(linear(clip_hidden, c->cfg.clip_dim, c->projc_w, c->projc_b, c->ctmp.p, C, B * M, C, c->cfg.clip_dim, false, nullptr, 0, st));
+    HIPRET(dlin(c, clip_hidden, c->cfg.clip_dim, c->projc_w, c->projc_b, c->ctmp.p, C, B * M, C, c->cfg.clip_dim, nullptr, 0, nullptr, 1, st));
     HIPRET(launch_layernorm(c->ctmp.p, c->normc_w, c->normc_b, cond_out, B * M, C, C, C, 1e-5f, st));
     return ER_OK;
 }
@@ -204,7 +235,7 @@ extern "C" int er_dit_encode_image(er_dit_ctx* c, const float* images, int B, in
     HIPRET(hipGetLastError());
     hipLaunchKernelGGL(clip_im2col_kernel, blocks((long long)B * NP * c->clip_kpad), dim3(256), 0, st, c->cpx.p, c->ccol.p, B, S, P, c->clip_kpad);
     HIPRET(hipGetLastError());
-    HIPRET(linear(c->ccol.p, c->clip_kpad, c->clip_patch_w, nullptr, c->cpatch.p, W, B * NP, W, c->clip_kpad, false, nullptr, 0, st));
+    HIPRET(dlin(c, c->ccol.p, c->clip_kpad, c->clip_patch_w, nullptr, c->cpatch.p, W, B * NP, W, c->clip_kpad, nullptr, 0, nullptr, 1, st));
     float* x = c->cx.p;
     hipLaunchKernelGGL(clip_assemble_kernel, blocks((long long)R * W), dim3(256), 0, st, c->cpatch.p, c->clip_cls, c->clip_pos, x, B, NP, W);
     HIPRET(hipGetLastError());
@@ -212,19 +243,19 @@ extern "C" int er_dit_encode_image(er_dit_ctx* c, const float* images, int B, in
     for (int l = 0; l < g.clip_layers; ++l) {           // CLIPEncoderLayer: pre-LN attention + pre-LN MLP, both residual
         const ClipLayerW& L = c->clip[l];
         HIPRET(launch_layernorm(x, L.ln1w, L.ln1b, c->ch.p, R, W, W, W, 1e-5f, st));
-        HIPRET(linear(c->ch.p, W, L.qw, L.qb, c->cq.p, W, R, W, W, false, nullptr, 0, st));
-        HIPRET(linear(c->ch.p, W, L.kw, L.kb, c->ck.p, W, R, W, W, false, nullptr, 0, st));
-        HIPRET(linear(c->ch.p, W, L.vw, L.vb, c->cv.p, W, R, W, W, false, nullptr, 0, st));
+        HIPRET(dlin(c, c->ch.p, W, L.qw, L.qb, c->cq.p, W, R, W, W, nullptr, 0, nullptr, 1, st));
+        HIPRET(dlin(c, c->ch.p, W, L.kw, L.kb, c->ck.p, W, R, W, W, nullptr, 0, nullptr, 1, st));
+        HIPRET(dlin(c, c->ch.p, W, L.vw, L.vb, c->cv.p, W, R, W, W, nullptr, 0, nullptr, 1, st));
         for (int b = 0; b < B; ++b) {
             const size_t o = (size_t)b * NT * W;
             ERCHK(attention_full(c->cq.p + o, W, c->ck.p + o, W, D, c->cv.p + o, W, D, c->catt.p + o, W, c->sc.p, H, D, NT, NT, false, st));
         }
-        HIPRET(linear(c->catt.p, W, L.ow, L.ob, x, W, R, W, W, false, x, W, st));
+        HIPRET(dlin(c, c->catt.p, W, L.ow, L.ob, x, W, R, W, W, x, W, nullptr, 1, st));
         HIPRET(launch_layernorm(x, L.ln2w, L.ln2b, c->ch.p, R, W, W, W, 1e-5f, st));
-        HIPRET(linear(c->ch.p, W, L.f1w, L.f1b, c->cf.p, F, R, F, W, false, nullptr, 0, st));
+        HIPRET(dlin(c, c->ch.p, W, L.f1w, L.f1b, c->cf.p, F, R, F, W, nullptr, 0, nullptr, 1, st));
         hipLaunchKernelGGL(gelu_kernel, blocks((long long)R * F), dim3(256), 0, st, c->cf.p, c->cf.p, (long long)R * F);
         HIPRET(hipGetLastError());
-        HIPRET(linear(c->cf.p, F, L.f2w, L.f2b, x, W, R, W, F, false, x, W, st));
+        HIPRET(dlin(c, c->cf.p, F, L.f2w, L.f2b, x, W, R, W, F, x, W, nullptr, 1, st));
     }
     HIPCHK(hipMemcpyAsync(out, x, (size_t)R * W * 4, hipMemcpyDeviceToDevice, st));
     return ER_OK;
@@ -235,14 +266,6 @@ static hipError_t dit_ln_mod(const float* x, float* y, int rows, int rows_per_ba
     hipLaunchKernelGGL((ln_modulate_rows_kernel<16>), dim3((rows + ER_NWAVES - 1) / ER_NWAVES), dim3(ER_WG), 0, st, x, y, rows,
                        rows_per_batch, table, tvec, t_bstride, t_cstride, shift_idx, scale_idx, 1e-6f);
     return hipGetLastError();
-}
-
-static hipError_t dit_gated_linear(const float* A, int lda, const float* W, const float* bias, float* C, int M, int N, int K,
-                                   const float* gate, int gate_rows, hipStream_t st) {   // C = C + gate_b * (A W^T + bias)
-    GemmArgs g = gemm_args_default();
-    g.A = A; g.B = W; g.C = C; g.bias = bias; g.resid = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = N; g.ldr = N;
-    g.gate = gate; g.gate_rows = gate_rows; g.gate_bstride = N;
-    return launch_gemm(g, 1, st);
 }
 
 // t_emb / t_adaln for B rows with timesteps already on the device (t_dev [B])
@@ -256,13 +279,13 @@ static int dit_time_embed(er_dit_ctx* c, int B, hipStream_t st) {
     ERCHK(ensure(c->tada, (size_t)B * 6 * C));
     hipLaunchKernelGGL(timestep_embed_kernel, dim3((B * 128 + 255) / 256), dim3(256), 0, st, c->t_dev.p, c->tin.p, B, 128);
     HIPRET(hipGetLastError());
-    HIPRET(linear(c->tin.p, 256, c->tp1_w, c->tp1_b, c->temb0.p, C, B, C, 256, false, nullptr, 0, st));
+    HIPRET(dlin(c, c->tin.p, 256, c->tp1_w, c->tp1_b, c->temb0.p, C, B, C, 256, nullptr, 0, nullptr, 1, st));
     hipLaunchKernelGGL(silu_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, c->temb0.p, c->temb1.p, (long long)B * C);
     HIPRET(hipGetLastError());
-    HIPRET(linear(c->temb1.p, C, c->tp2_w, c->tp2_b, c->temb.p, C, B, C, C, false, nullptr, 0, st));
+    HIPRET(dlin(c, c->temb1.p, C, c->tp2_w, c->tp2_b, c->temb.p, C, B, C, C, nullptr, 0, nullptr, 1, st));
     hipLaunchKernelGGL(silu_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, c->temb.p, c->tsil.p, (long long)B * C);
     HIPRET(hipGetLastError());
-    HIPRET(linear(c->tsil.p, C, c->adaln_w, c->adaln_b, c->tada.p, 6 * C, B, 6 * C, C, false, nullptr, 0, st));
+    HIPRET(dlin(c, c->tsil.p, C, c->adaln_w, c->adaln_b, c->tada.p, 6 * C, B, 6 * C, C, nullptr, 0, nullptr, 1, st));
     return 0;
 }
 
@@ -275,8 +298,8 @@ static int dit_cross_kv(er_dit_ctx* c, const float* cond, int B, int M, hipStrea
         const DitLayerW& L = c->layers[l];
         float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
         float* v2 = k2 + (size_t)B * M * C;
-        HIPRET(linear(cond, C, L.k2_w, L.k2_b, k2, C, B * M, C, C, false, nullptr, 0, st));
-        HIPRET(linear(cond, C, L.v2_w, L.v2_b, v2, C, B * M, C, C, false, nullptr, 0, st));
+        HIPRET(dlin(c, cond, C, L.k2_w, L.k2_b, k2, C, B * M, C, C, nullptr, 0, nullptr, 1, st));
+        HIPRET(dlin(c, cond, C, L.v2_w, L.v2_b, v2, C, B * M, C, C, nullptr, 0, nullptr, 1, st));
     }
     return 0;
 }
@@ -298,7 +321,7 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     ERCHK(dit_time_embed(c, B, st));
     float* x = c->x.p;
     // x = proj_in(x) + pos_embed                                                  dit.py:177-180
-    HIPRET(linear(xin, LD, c->proj_in_w, c->proj_in_b, x, C, R, C, LD, false, nullptr, 0, st));
+    HIPRET(dlin(c, xin, LD, c->proj_in_w, c->proj_in_b, x, C, R, C, LD, nullptr, 0, nullptr, 1, st));
     hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid((long long)R * C / 4)), dim3(ER_WG), 0, st, x, c->pos_embed, x, B, N, C, 0);
     HIPRET(hipGetLastError());
     for (int l = 0; l < g.num_layers; ++l) {
@@ -306,7 +329,7 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         // x = norm1(x) * (1 + scale_msa) + shift_msa   (chunks 0 = shift, 1 = scale, 2 = gate)     dit.py:129-132
         HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st));
         // x = x + gate_msa * attn1(x)                                               dit.py:133
-        HIPRET(linear(x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, false, nullptr, 0, st));
+        HIPRET(dlin(c, x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, st));
         for (int b = 0; b < B; ++b) {
             float* base = c->qkv.p + (size_t)b * N * 3 * C;
             ERCHK(attention_full(base, 3 * C, base + C, 3 * C, D, base + 2 * C, 3 * C, D, c->att.p + (size_t)b * N * C, C, c->sc.p,
@@ -314,27 +337,27 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         }
         hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 2);
         HIPRET(hipGetLastError());
-        HIPRET(dit_gated_linear(c->att.p, C, L.o_w, L.o_b, x, R, C, C, c->gate.p, N, st));
+        HIPRET(dlin(c, c->att.p, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, st));
         // x = x + attn2(x, c)                                                       dit.py:135
-        HIPRET(linear(x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, false, nullptr, 0, st));
+        HIPRET(dlin(c, x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, st));
         const float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
         const float* v2 = k2 + (size_t)B * M * C;
         for (int b = 0; b < B; ++b)
             ERCHK(attention_full(c->q2.p + (size_t)b * N * C, C, k2 + (size_t)b * M * C, C, D, v2 + (size_t)b * M * C, C, D,
                                  c->att.p + (size_t)b * N * C, C, c->sc.p, H, D, N, M, false, st));
-        HIPRET(linear(c->att.p, C, L.o2_w, L.o2_b, x, C, R, C, C, false, x, C, st));
+        HIPRET(dlin(c, c->att.p, C, L.o2_w, L.o2_b, x, C, R, C, C, x, C, nullptr, 1, st));
         // x = norm2(x) * (1 + scale_mlp) + shift_mlp; x = x + gate_mlp * ff(x)     dit.py:137-139
         HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 3, 4, st));
-        HIPRET(linear(x, C, L.ff0_w, L.ff0_b, c->u.p, 8 * C, R, 8 * C, C, false, nullptr, 0, st));
+        HIPRET(dlin(c, x, C, L.ff0_w, L.ff0_b, c->u.p, 8 * C, R, 8 * C, C, nullptr, 0, nullptr, 1, st));
         hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)R * 4 * C)), dim3(ER_WG), 0, st, c->u.p, c->g.p, (long long)R, 4 * C);
         HIPRET(hipGetLastError());
         hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 5);
         HIPRET(hipGetLastError());
-        HIPRET(dit_gated_linear(c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, R, C, 4 * C, c->gate.p, N, st));
+        HIPRET(dlin(c, c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, c->gate.p, N, st));
     }
     // shift, scale = scale_shift_table + t_emb; x = norm_out(x) * (1 + scale) + shift; proj_out     dit.py:190-194
     HIPRET(dit_ln_mod(x, x, R, N, c->sst2, c->temb.p, (long long)C, 0, 0, 1, st));
-    HIPRET(linear(x, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, false, nullptr, 0, st));
+    HIPRET(dlin(c, x, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, nullptr, 0, nullptr, 1, st));
     return 0;
 }
 

@@ -46,6 +46,41 @@ constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = GBM + 4;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// epilogue shared by the fp32 and fp16-input kernels: C/D fragment map of the 32x32 MFMA (dtype independent):
+// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const f32x16 (&acc)[2][2], int m0, int n0, int wm,
+                                              int wn, int kh, int li) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int gn = n0 + wn * 64 + j * 32 + li;
+                if (gm >= g.M || gn >= g.N) continue;
+                float v = acc[i][j][r];
+                if (g.div != 0.f) v = v / g.div;
+                if (g.bias) v += g.bias[gn];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.gate) v *= g.gate[(long long)(gm / g.gate_rows) * g.gate_bstride + gn];
+                if (g.resid) v += g.resid[(long long)gm * g.ldr + gn];
+                if (g.epi == GEPI_PLAIN) {
+                    C[(long long)gm * g.ldc + gn] = v;
+                } else {
+                    const int which = gn / g.hidden, c = gn - which * g.hidden;
+                    if (which == 0) {
+                        g.q[(long long)gm * g.hidden + c] = v;
+                    } else {
+                        const int b = gm / g.S, s = gm - b * g.S;
+                        const int h = c / g.head_dim, d = c - h * g.head_dim;
+                        float* cache = (which == 1) ? g.kcache : g.vcache;
+                        cache[(long long)b * g.kv_bstride + ((long long)h * g.l_cap + s) * g.head_dim + d] = v;
+                    }
+                }
+            }
+}
+
 __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
@@ -150,36 +185,92 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: C/D fragment map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    gemm_epilogue(g, C, acc, m0, n0, wm, wn, kh, li);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp16-input variant for the compute-bound front-end GEMMs (DiT / CLIP linears in fast mode):
+//   C[M,N] = epilogue( fp16(A[M,K] fp32) . fp16 W[N,K]^T ), fp32 accumulate on v_mfma_f32_32x32x16_f16
+// (16x the fp32 matrix rate).  Tile 128x128x32; A is rounded to fp16 on its way into LDS, W is stored fp16.
+// LDS rows are [row][32 k] halves padded to 80 bytes so the 16-byte operand reads (lane l: row l&31,
+// k-block (l>>5)*8) hit 16 distinct 4-bank slots per 16-lane group.  Both operands use the same
+// (lane-half, element) -> k assignment, so the product sum is independent of the instruction's internal k order.
+constexpr int HBK = 32, HLD = 40;            // halves per LDS row (32 + 8 pad)
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[GBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[GBN * HLD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const float* A = g.A;
+    const _Float16* B = reinterpret_cast<const _Float16*>(g.B);
+    const int nk = g.K / HBK;
+    f32x4 ra[4];
+    f32x4 rb[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * HBK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
+            const int gm = m0 + row;
+            ra[u] = (gm < g.M) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * c4) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
+            const int gn = n0 + row;
+            rb[u] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
+            h16x4 hv = {(_Float16)ra[u].x, (_Float16)ra[u].y, (_Float16)ra[u].z, (_Float16)ra[u].w};
+            *reinterpret_cast<h16x4*>(&As[row * HLD + 4 * c4]) = hv;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
+            *reinterpret_cast<f32x4*>(&Bs[row * HLD + 8 * c8]) = rb[u];
+        }
+    };
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int gn = n0 + wn * 64 + j * 32 + li;
-                if (gm >= g.M || gn >= g.N) continue;
-                float v = acc[i][j][r];
-                if (g.div != 0.f) v = v / g.div;
-                if (g.bias) v += g.bias[gn];
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.gate) v *= g.gate[(long long)(gm / g.gate_rows) * g.gate_bstride + gn];
-                if (g.resid) v += g.resid[(long long)gm * g.ldr + gn];
-                if (g.epi == GEPI_PLAIN) {
-                    C[(long long)gm * g.ldc + gn] = v;
-                } else {
-                    const int which = gn / g.hidden, c = gn - which * g.hidden;
-                    if (which == 0) {
-                        g.q[(long long)gm * g.hidden + c] = v;
-                    } else {
-                        const int b = gm / g.S, s = gm - b * g.S;
-                        const int h = c / g.head_dim, d = c - h * g.head_dim;
-                        float* cache = (which == 1) ? g.kcache : g.vcache;
-                        cache[(long long)b * g.kv_bstride + ((long long)h * g.l_cap + s) * g.head_dim + d] = v;
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (nk > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+    const int kh = lane >> 5, li = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            const int ko = ks * 16 + kh * 8;
+            const h16x8 a0 = *reinterpret_cast<const h16x8*>(&As[(wm * 64 + li) * HLD + ko]);
+            const h16x8 a1 = *reinterpret_cast<const h16x8*>(&As[(wm * 64 + 32 + li) * HLD + ko]);
+            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[(wn * 64 + li) * HLD + ko]);
+            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[(wn * 64 + 32 + li) * HLD + ko]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) store_tile();
+        __syncthreads();
+    }
+    gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);
 }
 
 inline GemmArgs gemm_args_default() {
@@ -187,6 +278,12 @@ inline GemmArgs gemm_args_default() {
     g.Z2 = 1;
     g.epi = GEPI_PLAIN;
     return g;
+}
+
+inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT only, K % 32 == 0, B = fp16 weights
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, 1);
+    hipLaunchKernelGGL(gemm_f16_mfma_kernel, grid, dim3(ER_WG), 0, st, g);
+    return hipGetLastError();
 }
 
 inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {

@@ -57,23 +57,37 @@ inline hipError_t launch_layernorm(const float* x, const float* w, const float* 
 // columns [n_valid, ld_pad) are written as 0 so the following P.V GEMM may run over a
 // 16-padded K.  grid (rows, batch), one workgroup per row.
 __global__ __launch_bounds__(ER_WG) void softmax_rows_kernel(float* s, int rows, int cols, long long ld, int ld_pad,
-                                                             long long batch_stride, int causal, int causal_off) {
+                                                             long long batch_stride, int causal, int causal_off, int use_lds) {
     __shared__ float red[8];
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];   // use_lds: the row is staged here -> 1 read + 1 write of HBM
     const int r = blockIdx.x, tid = threadIdx.x;
     float* row = s + blockIdx.y * batch_stride + (long long)r * ld;
     const int nv = causal ? min(cols, r + 1 + causal_off) : cols;
+    float* w = use_lds ? rowbuf : row;          // same per-thread element order either way: identical results
     float m = -INFINITY;
-    for (int c = tid; c < nv; c += ER_WG) m = fmaxf(m, row[c]);
+    for (int c = tid; c < nv; c += ER_WG) {
+        const float v = row[c];
+        if (use_lds) rowbuf[c] = v;
+        m = fmaxf(m, v);
+    }
     m = block_max(m, red);
     float l = 0.f;
     for (int c = tid; c < nv; c += ER_WG) {
-        const float e = expf(row[c] - m);
-        row[c] = e;
+        const float e = expf(w[c] - m);
+        w[c] = e;
         l += e;
     }
     l = block_sum(l, red);
-    for (int c = tid; c < nv; c += ER_WG) row[c] = row[c] / l;
+    for (int c = tid; c < nv; c += ER_WG) row[c] = w[c] / l;
     for (int c = nv + tid; c < ld_pad; c += ER_WG) row[c] = 0.f;
+}
+
+inline hipError_t launch_softmax_rows(float* s, int rows, int cols, long long ld, int ld_pad, long long batch_stride, int batch,
+                                      int causal, int causal_off, hipStream_t st) {
+    const int use_lds = cols <= 15 * 1024;       // <= 60 KiB of LDS; longer rows fall back to in-place passes
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows, batch), dim3(ER_WG), use_lds ? (size_t)cols * sizeof(float) : 0, st, s, rows,
+                       cols, ld, ld_pad, batch_stride, causal, causal_off, use_lds);
+    return hipGetLastError();
 }
 
 // GEGLU (core/transformer/point.py:68-71): out[m, j] = u[m, j] * gelu_erf(u[m, F + j]).

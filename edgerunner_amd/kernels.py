@@ -51,6 +51,17 @@ def gemm(a, b, bias=None, resid=None, b_is_kn=False, relu=False, div=0.0, m=None
     return c
 
 
+def gemm_f16(a, w_half, bias=None, resid=None, relu=False):
+    """C = relu?(fp16(A) . W^T + bias) (+resid) on the fp16-input MFMA path; a fp32 [M,K], w_half fp16 [N,K]."""
+    lib = native.load_library()
+    M, K = a.shape
+    N = w_half.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    native.check(lib.er_k_gemm_f16(native.ptr(a), native.ptr(w_half), native.ptr(bias), native.ptr(resid), native.ptr(c), M, N, K,
+                                   a.stride(0), w_half.stride(0), c.stride(0), int(relu), _st()), "er_k_gemm_f16")
+    return c
+
+
 def layernorm(x, w, b, eps=1e-5):
     lib = native.load_library()
     y = torch.empty_like(x)

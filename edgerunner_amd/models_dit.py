@@ -21,18 +21,22 @@ CLIP_DIM = 1280   # laion/CLIP-ViT-H-14 hidden width (core/models_dit.py:56)
 
 
 class MDiT:
-    def __init__(self, opt, device="cuda:0", clip_layers: int = 32):
+    def __init__(self, opt, device="cuda:0", clip_layers: int = 32, precision: str = "fp32"):
         """clip_layers: depth of the CLIP ViT image encoder to expect in the checkpoint (32 = ViT-H/14 as in the
         reference; 0 = no image encoder: get_cond then takes its last_hidden_state directly)."""
         self.opt = opt
         self.clip_layers = clip_layers
+        if precision not in ("fp32", "fp16"):
+            raise ValueError(precision)
+        self.precision = precision      # 'fp16': every Linear on the fp16-input matrix cores (the reference's GPU dtype)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise native.NativeError("MDiT needs a HIP device; there is no CPU fallback")
         self.lib = native.load_library()
         cfg = native.ErDitConfig(hidden_dim=opt.dit_hidden_dim, num_heads=opt.dit_num_heads, num_layers=opt.dit_num_layers,
                                  latent_size=opt.point_latent_size, latent_dim=opt.point_latent_dim, clip_dim=CLIP_DIM,
-                                 clip_layers=clip_layers, clip_heads=16, clip_mlp_dim=5120, clip_image_size=224, clip_patch=14)
+                                 clip_layers=clip_layers, clip_heads=16, clip_mlp_dim=5120, clip_image_size=224, clip_patch=14,
+                                 weight_dtype=native.ER_F32 if precision == "fp32" else native.ER_F16)
         self._ctx = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         native.check(self.lib.er_dit_create(C.byref(cfg), idx, C.byref(self._ctx)), "er_dit_create")

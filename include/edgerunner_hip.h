@@ -162,6 +162,7 @@ typedef struct {
     int32_t clip_dim;                            /* width of the image encoder's last_hidden_state (1280)   */
     int32_t clip_layers, clip_heads, clip_mlp_dim; /* CLIP ViT-H/14: 32 / 16 / 5120; clip_layers = 0: encoder not loaded */
     int32_t clip_image_size, clip_patch;         /* 224 / 14                                                  */
+    int32_t weight_dtype;                        /* ER_F32 (exact) or ER_F16: every Linear on fp16-input MFMA, fp32 accumulate */
 } er_dit_config;
 typedef struct er_dit_ctx er_dit_ctx;
 int er_dit_create(const er_dit_config* cfg, int device, er_dit_ctx** out);
@@ -214,6 +215,9 @@ int er_k_attn_decode(const float* q_dev, const void* k_dev, const void* v_dev, c
 int er_k_gemm(const float* a_dev, const float* b_dev, const float* bias_dev, const float* resid_dev,
               float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int b_is_kn, int relu,
               float div, void* stream);
+/* C[M,N] = relu?(fp16(A fp32 [M,K]) . W fp16 [N,K]^T + bias) (+resid): the fp16-input MFMA GEMM (k % 32 == 0) */
+int er_k_gemm_f16(const float* a_dev, const void* w_half_dev, const float* bias_dev, const float* resid_dev,
+                  float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int relu, void* stream);
 int er_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
                    int rows, int cols, float eps, void* stream);
 /* rows of scores[rows, ld]: softmax over the first n_valid(row) columns (causal: row+1+causal_offset), zeros after */

@@ -73,8 +73,38 @@ def _ln(sd, prefix, x):
     return F.layer_norm(x, (x.shape[-1],), sd[f"{prefix}.weight"], sd[f"{prefix}.bias"], LN_EPS)
 
 
+_LINEAR_INPUT_ROUND = None     # test helper: emulate the fp16-input matrix path (see linear_input_rounding)
+
+
+class linear_input_rounding:
+    """Context manager for the fast-mode emulation of the DiT / CLIP front-end: inside it every Linear (and the patch
+    convolution) sees its activation rounded through `dtype`, like the fp16-input MFMA GEMM does; arithmetic stays fp32.
+    Pair it with weights rounded by :func:`round_linear_weights`."""
+
+    def __init__(self, dtype=torch.float16):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _LINEAR_INPUT_ROUND
+        self._old, _LINEAR_INPUT_ROUND = _LINEAR_INPUT_ROUND, self.dtype
+
+    def __exit__(self, *a):
+        global _LINEAR_INPUT_ROUND
+        _LINEAR_INPUT_ROUND = self._old
+
+
+def round_linear_weights(sd: StateDict, dtype=torch.float16) -> StateDict:
+    """Every >= 2-D '.weight' except lookup tables, rounded through `dtype` (kept fp32)."""
+    return {k: (v.to(dtype).float() if (k.endswith(".weight") and v.dim() >= 2 and "position_embedding" not in k) else v)
+            for k, v in sd.items()}
+
+
+def _rin(x):
+    return x if _LINEAR_INPUT_ROUND is None else x.to(_LINEAR_INPUT_ROUND).float()
+
+
 def _lin(sd, prefix, x):
-    return F.linear(x, sd[f"{prefix}.weight"], sd.get(f"{prefix}.bias"))
+    return F.linear(_rin(x), sd[f"{prefix}.weight"], sd.get(f"{prefix}.bias"))
 
 
 def point_encoder_embed(sd: StateDict, x, num_heads: int):
@@ -486,7 +516,7 @@ def clip_vision_forward(sd: StateDict, pixel_values, num_heads: int = 16, prefix
     """CLIPVisionTransformer.forward -> last_hidden_state [B, 257, width] (no post_layernorm)."""
     B = pixel_values.shape[0]
     w = sd[f"{prefix}.embeddings.patch_embedding.weight"]
-    x = F.conv2d(pixel_values, w, stride=w.shape[-1]).flatten(2).transpose(1, 2)
+    x = F.conv2d(_rin(pixel_values), w, stride=w.shape[-1]).flatten(2).transpose(1, 2)
     cls = sd[f"{prefix}.embeddings.class_embedding"].expand(B, 1, -1)
     x = torch.cat([cls, x], dim=1) + sd[f"{prefix}.embeddings.position_embedding.weight"]
     C = x.shape[-1]

@@ -23,7 +23,8 @@ def main():
     opt = dataclasses.replace(config_defaults["DiT"], generate_mode="greedy", cond_mode="point_latent")
     dev = "cuda:0"
     t0 = time.time()
-    mdit = MDiT(opt, dev, clip_layers=32)
+    precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+    mdit = MDiT(opt, dev, clip_layers=32, precision=precision)
     sd = W.make_dit_state_dict(opt, 0, "perturbed")
     sd.update(W.make_clip_state_dict(32, 0, "perturbed"))
     mdit.load_state_dict(sd, strict=True)

@@ -125,3 +125,31 @@ def test_unbuilt_pieces_fail_loudly(setup):
         m.get_cond(torch.rand(1, 3, 512, 512))
     with pytest.raises(NotImplementedError):
         m.run(clip_hidden.to(DEV), latents=noise.to(DEV))
+
+
+def test_fast_mode_fp16_mfma_vs_emulation(setup):
+    """precision='fp16': every Linear of CLIP / proj_cond / DiT on the fp16-input matrix cores.  Must match the oracle
+    with fp16-rounded weights AND fp16-rounded Linear inputs (fp32 math otherwise); distance to fp32 is reported."""
+    import arae_oracle as O
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models_dit import MDiT
+    opt, sd, m32, g, clip_hidden, noise, x = setup
+    sd_all = dict(sd)
+    sd_all.update(W.make_clip_state_dict(2, 0, "perturbed"))
+    m = MDiT(opt, DEV, clip_layers=2, precision="fp16")
+    m.load_state_dict(sd_all, strict=True)
+    sd_h = O.round_linear_weights(sd_all)
+    gen = torch.Generator().manual_seed(2024)
+    img = torch.rand(1, 3, 384, 384, generator=gen)
+    nz = torch.randn(1, 2048, 64, generator=gen)
+    with O.linear_input_rounding(torch.float16):
+        want_cond = O.mdit_get_cond(sd_h, img)
+        want_lat = O.mdit_run(sd_h, want_cond, nz, opt.dit_num_heads, num_inference_steps=4, guidance_scale=7.5)
+    ref_lat = O.mdit_run(sd_all, O.mdit_get_cond(sd_all, img), nz, opt.dit_num_heads, num_inference_steps=4, guidance_scale=7.5)
+    cond = m.get_cond(img.to(DEV))
+    lat = m.run(img.to(DEV), num_inference_steps=4, guidance_scale=7.5, noise=nz.to(DEV))
+    e_cond = float((cond.cpu() - want_cond).abs().max())
+    e_lat = float((lat.cpu() - want_lat).abs().max())
+    drift = float((lat.cpu() - ref_lat).abs().max())
+    print(f"fp16 MFMA front-end: cond err vs emulation {e_cond:.3e}, latents err {e_lat:.3e}; latents vs fp32 path {drift:.3e}")
+    assert e_cond < 2e-3 and e_lat < 5e-3

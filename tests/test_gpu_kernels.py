@@ -173,6 +173,23 @@ def test_gemm_scale_div():
     close(c, ref, 1e-5, 1e-5, "scores / sqrt(D)")
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (4096, 1024, 1024), (514, 3072, 1024), (257, 1280, 5120), (77, 200, 608)])
+def test_gemm_f16_input_mfma(M, N, K):
+    """fp16-input MFMA GEMM == fp32 math on fp16-rounded operands (asymmetric operands catch a transposed map)."""
+    from edgerunner_amd import kernels as K_
+    a, w = rnd(M, K, seed=70), rnd(N, K, seed=71, scale=0.05)
+    bias, resid = rnd(N, seed=72), rnd(M, N, seed=73)
+    wh = w.half()
+    ref = a.half().double() @ wh.double().T + bias.double()
+    c = K_.gemm_f16(a, wh, bias, resid)
+    close(c, ref + resid.double(), 1e-5 + 2e-7 * K, 1e-5, "gemm f16")
+    c2 = K_.gemm_f16(a, wh, bias, None, relu=True)
+    close(c2, torch.relu(ref), 1e-5 + 2e-7 * K, 1e-5, "gemm f16 relu")
+    eye = torch.eye(256, device=DEV)
+    wq = ((torch.arange(256 * 256, device=DEV, dtype=torch.float32).view(256, 256) % 509) / 8.0).half()
+    assert torch.equal(K_.gemm_f16(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
+
+
 # ------------------------------------------------------------------ row ops
 @pytest.mark.parametrize("cols", [1536, 1024])
 def test_layernorm_rows(cols):
