@@ -19,6 +19,7 @@
 #include "k_gemv.h"
 #include "k_head.h"
 #include "k_rowops.h"
+#include "k_flash_attn.h"
 #include "meto_decode.h"
 #include "meto_encode.h"
 
@@ -1156,6 +1157,18 @@ extern "C" int er_k_gemm_f16(const float* a, const void* w, const float* bias, c
     g.A = a; g.B = reinterpret_cast<const float*>(w); g.C = cc; g.bias = bias; g.resid = resid; g.M = m; g.N = n; g.K = k;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.relu = relu;
     HIPRET(launch_gemm_f16(g, (hipStream_t)stream));
+    return ER_OK;
+}
+
+extern "C" int er_k_flash_attn_f16(const float* q, const float* k, const float* v, float* o, int B, int H, int N, int M,
+                                   void* stream) {
+    // q/k/v/o: [B, rows, H*64] fp32, heads side by side in a row (the layout the projections produce)
+    FlashArgs a{};
+    a.Q = q; a.K = k; a.V = v; a.O = o; a.N = N; a.M = M;
+    a.ldq = a.ldk = a.ldv = a.ldo = H * FA_D;
+    a.qs_b = (long long)N * H * FA_D; a.os_b = a.qs_b; a.ks_b = (long long)M * H * FA_D; a.vs_b = a.ks_b;
+    a.head_stride = FA_D; a.scale = 1.0f / sqrtf((float)FA_D);
+    HIPRET(launch_flash_attn_f16(a, H, B, (hipStream_t)stream));
     return ER_OK;
 }
 

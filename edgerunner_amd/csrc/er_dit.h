@@ -316,7 +316,11 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     ERCHK(ensure(c->q2, (size_t)R * C));
     ERCHK(ensure(c->u, (size_t)R * 8 * C));
     ERCHK(ensure(c->g, (size_t)R * 4 * C));
-    ERCHK(ensure(c->sc, (size_t)H * N * ldS));
+    // fp16 mode: fused attention on the fp16 matrix cores (no score matrix in HBM); ER_DIT_NO_FLASH=1 keeps the
+    // materialised fp32 scores path for A/B measurements
+    static const bool no_flash = getenv("ER_DIT_NO_FLASH") != nullptr;
+    const bool flash = c->fast && D == FA_D && !no_flash;
+    if (!flash) ERCHK(ensure(c->sc, (size_t)H * N * ldS));
     ERCHK(ensure(c->gate, (size_t)B * C));
     ERCHK(dit_time_embed(c, B, st));
     float* x = c->x.p;
@@ -330,10 +334,19 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st));
         // x = x + gate_msa * attn1(x)                                               dit.py:133
         HIPRET(dlin(c, x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, st));
-        for (int b = 0; b < B; ++b) {
-            float* base = c->qkv.p + (size_t)b * N * 3 * C;
-            ERCHK(attention_full(base, 3 * C, base + C, 3 * C, D, base + 2 * C, 3 * C, D, c->att.p + (size_t)b * N * C, C, c->sc.p,
-                                 H, D, N, N, false, st));
+        if (flash) {
+            FlashArgs fa{};
+            fa.Q = c->qkv.p; fa.K = c->qkv.p + C; fa.V = c->qkv.p + 2 * C; fa.O = c->att.p; fa.N = N; fa.M = N;
+            fa.ldq = fa.ldk = fa.ldv = 3 * C; fa.ldo = C;
+            fa.qs_b = fa.ks_b = fa.vs_b = (long long)N * 3 * C; fa.os_b = (long long)N * C;
+            fa.head_stride = D; fa.scale = 1.0f / sqrtf((float)D);
+            HIPRET(launch_flash_attn_f16(fa, H, B, st));
+        } else {
+            for (int b = 0; b < B; ++b) {
+                float* base = c->qkv.p + (size_t)b * N * 3 * C;
+                ERCHK(attention_full(base, 3 * C, base + C, 3 * C, D, base + 2 * C, 3 * C, D, c->att.p + (size_t)b * N * C, C,
+                                     c->sc.p, H, D, N, N, false, st));
+            }
         }
         hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 2);
         HIPRET(hipGetLastError());
@@ -342,9 +355,18 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         HIPRET(dlin(c, x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, st));
         const float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
         const float* v2 = k2 + (size_t)B * M * C;
-        for (int b = 0; b < B; ++b)
-            ERCHK(attention_full(c->q2.p + (size_t)b * N * C, C, k2 + (size_t)b * M * C, C, D, v2 + (size_t)b * M * C, C, D,
-                                 c->att.p + (size_t)b * N * C, C, c->sc.p, H, D, N, M, false, st));
+        if (flash) {
+            FlashArgs fa{};
+            fa.Q = c->q2.p; fa.K = k2; fa.V = v2; fa.O = c->att.p; fa.N = N; fa.M = M;
+            fa.ldq = fa.ldk = fa.ldv = fa.ldo = C;
+            fa.qs_b = fa.os_b = (long long)N * C; fa.ks_b = fa.vs_b = (long long)M * C;
+            fa.head_stride = D; fa.scale = 1.0f / sqrtf((float)D);
+            HIPRET(launch_flash_attn_f16(fa, H, B, st));
+        } else {
+            for (int b = 0; b < B; ++b)
+                ERCHK(attention_full(c->q2.p + (size_t)b * N * C, C, k2 + (size_t)b * M * C, C, D, v2 + (size_t)b * M * C, C, D,
+                                     c->att.p + (size_t)b * N * C, C, c->sc.p, H, D, N, M, false, st));
+        }
         HIPRET(dlin(c, c->att.p, C, L.o2_w, L.o2_b, x, C, R, C, C, x, C, nullptr, 1, st));
         // x = norm2(x) * (1 + scale_mlp) + shift_mlp; x = x + gate_mlp * ff(x)     dit.py:137-139
         HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 3, 4, st));

@@ -62,6 +62,17 @@ def gemm_f16(a, w_half, bias=None, resid=None, relu=False):
     return c
 
 
+def flash_attn_f16(q, k, v, heads):
+    """q [B,N,H*64], k/v [B,M,H*64] fp32 -> softmax(q k^T / 8) v, [B,N,H*64] (fp16 operands, fp32 accumulate)."""
+    lib = native.load_library()
+    B, N, _ = q.shape
+    M = k.shape[1]
+    o = torch.empty_like(q)
+    native.check(lib.er_k_flash_attn_f16(native.ptr(q), native.ptr(k), native.ptr(v), native.ptr(o), B, heads, N, M, _st()),
+                 "er_k_flash_attn_f16")
+    return o
+
+
 def layernorm(x, w, b, eps=1e-5):
     lib = native.load_library()
     y = torch.empty_like(x)

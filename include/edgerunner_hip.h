@@ -218,6 +218,9 @@ int er_k_gemm(const float* a_dev, const float* b_dev, const float* bias_dev, con
 /* C[M,N] = relu?(fp16(A fp32 [M,K]) . W fp16 [N,K]^T + bias) (+resid): the fp16-input MFMA GEMM (k % 32 == 0) */
 int er_k_gemm_f16(const float* a_dev, const void* w_half_dev, const float* bias_dev, const float* resid_dev,
                   float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int relu, void* stream);
+/* softmax(q k^T / 8) v, head_dim 64, non-causal, fp16 operands / fp32 accumulate; q,o [B,N,H*64], k,v [B,M,H*64] fp32 */
+int er_k_flash_attn_f16(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch,
+                        int heads, int n_queries, int m_keys, void* stream);
 int er_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
                    int rows, int cols, float eps, void* stream);
 /* rows of scores[rows, ld]: softmax over the first n_valid(row) columns (causal: row+1+causal_offset), zeros after */

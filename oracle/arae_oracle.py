@@ -403,6 +403,19 @@ def timestep_embedding(t, num_channels=256, max_period=10000):
     return torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
 
 
+def _attention_f16_emulation(q, k, v, dtype):
+    """Fast-mode emulation of the fused attention kernel (csrc/k_flash_attn.h): q, k, v and the unnormalised
+    probabilities pass through `dtype`, everything else is fp32.  (The kernel rounds p against the running row
+    maximum of its key tiles, this against the final one: same to within an fp16 ulp of p.)"""
+    B, N, H, D = q.shape
+    r = lambda t: t.to(dtype).float()
+    qh, kh, vh = (r(t).transpose(1, 2) for t in (q, k, v))                # [B,H,*,D]
+    s = (qh @ kh.transpose(-1, -2)) * (1.0 / D ** 0.5)
+    p = torch.exp(s - s.amax(dim=-1, keepdim=True))
+    o = (r(p) @ vh) / p.sum(dim=-1, keepdim=True)
+    return o.transpose(1, 2).contiguous()
+
+
 def _mha(sd, prefix, xq, ctx, num_heads, fused_qkv):
     """SelfAttention (attention.py:98-121, fused qkv_proj) / CrossAttention (:124-153)."""
     B, N, C = xq.shape
@@ -416,7 +429,10 @@ def _mha(sd, prefix, xq, ctx, num_heads, fused_qkv):
         q = _lin(sd, f"{prefix}.q_proj", xq).reshape(B, N, num_heads, D)
         k = _lin(sd, f"{prefix}.k_proj", ctx).reshape(B, M, num_heads, D)
         v = _lin(sd, f"{prefix}.v_proj", ctx).reshape(B, M, num_heads, D)
-    a = attention_naive(q, k, v, causal=False)
+    if _LINEAR_INPUT_ROUND is not None and D == 64:
+        a = _attention_f16_emulation(q, k, v, _LINEAR_INPUT_ROUND)
+    else:
+        a = attention_naive(q, k, v, causal=False)
     return _lin(sd, f"{prefix}.out_proj", a.reshape(B, N, -1))
 
 

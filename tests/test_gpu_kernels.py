@@ -190,6 +190,18 @@ def test_gemm_f16_input_mfma(M, N, K):
     assert torch.equal(K_.gemm_f16(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
 
 
+@pytest.mark.parametrize("B,H,N,M", [(1, 16, 2048, 2048), (2, 16, 2048, 257), (1, 2, 100, 70), (1, 1, 33, 1)])
+def test_flash_attn_f16(B, H, N, M):
+    from edgerunner_amd import kernels as K_
+    q, k, v = rnd(B, N, H * 64, seed=80), rnd(B, M, H * 64, seed=81), rnd(B, M, H * 64, seed=82)
+    k[:, M // 2] *= 3.0                                     # a spiky key row forces the running-max rescale
+    o = K_.flash_attn_f16(q, k, v, H)
+    qh, kh, vh = (t.half().double().view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, dim=-1)
+    ref = (p @ vh).transpose(1, 2).reshape(B, N, H * 64)
+    close(o, ref, 4e-3, 4e-3, "flash attention (fp16 P)")   # P is rounded to fp16 before P.V
+
+
 # ------------------------------------------------------------------ row ops
 @pytest.mark.parametrize("cols", [1536, 1024])
 def test_layernorm_rows(cols):
