@@ -17,6 +17,7 @@
 #include "k_attn_decode.h"
 #include "k_gemm.h"
 #include "k_gemv.h"
+#include "k_gemv_mfma.h"
 #include "k_head.h"
 #include "k_rowops.h"
 #include "k_flash_attn.h"
@@ -103,13 +104,17 @@ struct er_ctx {
     // hipGraph of one step
     hipGraphExec_t step_exec = nullptr;
     bool use_graph = true;
-    bool batched = false;     // B > 4 (or ER_FORCE_BATCHED=1): weights streamed once per 16 rows
+    bool batched = false;     // B > 4 (or ER_FORCE_BATCHED=1): weights streamed once per pass of 32 rows (matrix cores)
+    bool batched_valu = false;   // ER_BATCHED_VALU=1: the older VALU kernels (one pass per 16 rows), kept for A/B runs
+    float* skpart = nullptr;  // split-K partials of the batched out_proj / fc2 / lm_head
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
     Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp;
 };
+
+constexpr int NBM = 32;   // batch rows per pass of the matrix-core decode projections (k_gemv_mfma.h)
 
 static int ensure(Buf& b, size_t n) {
     if (b.n >= n) return 0;
@@ -220,6 +225,8 @@ static void free_kv(er_ctx* c) {
                     (void*)c->abuf, (void*)c->fbuf, (void*)c->logits, (void*)c->part})
         if (p) hipFree(p);
     c->kc = c->vc = c->ypre = c->hbuf = c->ypre1 = c->h1buf = c->qbuf = c->abuf = c->fbuf = c->logits = c->part = nullptr;
+    if (c->skpart) hipFree(c->skpart);
+    c->skpart = nullptr;
     if (c->state_block) hipFree(c->state_block);
     if (c->d_params) hipFree(c->d_params);
     if (c->d_ids_tmp) hipFree(c->d_ids_tmp);
@@ -444,6 +451,7 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     HIPCHK(hipMalloc(&c->fbuf, b * g.intermediate_dim * 4));
     HIPCHK(hipMalloc(&c->logits, b * g.vocab_size * 4));
     HIPCHK(hipMalloc(&c->part, b * H * S * (D + 2) * 4));
+    HIPCHK(hipMalloc(&c->skpart, (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
     c->st.tok = sb; c->st.pos = sb + b; c->st.counter = sb + 2 * b; c->st.ngen = sb + 3 * b;
@@ -456,6 +464,8 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     c->have_hidden = false;
     const char* fb = getenv("ER_FORCE_BATCHED");
     c->batched = batch > 4 || (fb && fb[0] == '1');
+    const char* bv = getenv("ER_BATCHED_VALU");
+    c->batched_valu = bv && bv[0] == '1';
     return ER_OK;
 }
 
@@ -529,6 +539,24 @@ static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) 
     }
     return hipSuccess;
 }
+template <typename WT, int EPI>
+static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st) {
+    for (int b = 0; b < B; b += NBM) {
+        const int nb = (B - b) < NBM ? (B - b) : NBM;
+        GemvArgs g = a;
+        g.xin += (long long)b * K;
+        if (g.pos) g.pos += b;
+        if (g.out) g.out += (long long)b * a.N;
+        if (g.resid) g.resid += (long long)b * a.N;
+        if (g.q) g.q += (long long)b * a.hidden;
+        const long long kvb = (long long)b * a.kv_bstride * (a.kv_half ? 2 : 4);
+        if (g.kcache) g.kcache = (char*)g.kcache + kvb;
+        if (g.vcache) g.vcache = (char*)g.vcache + kvb;
+        hipError_t e = launch_gemv_mfma<WT, EPI>(g, nb, K, part, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 template <int PRO>
 static hipError_t prep_rows(const GemvArgs& a, int B, hipStream_t st) {
     hipLaunchKernelGGL((prep_rows_kernel<PRO>), dim3(B), dim3(ER_WG), 0, st, a);
@@ -588,6 +616,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->hbuf;
+                if (!c->batched_valu) return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, c->skpart, st);   // 144 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_QKV>(a, B, H, st);   // 4608 rows = 192 workgroups x 24: one round
             }
             if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
@@ -598,6 +627,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
+            // (48 row tiles would leave the matrix-core kernel on 48 CUs: the narrow out_proj stays on the VALU kernel)
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
             return gemv_rw<WT, 1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st);
         }
@@ -609,6 +639,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->h1buf;
+                if (!c->batched_valu) return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, c->skpart, st);   // 192 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_RELU>(a, B, H, st);   // 6144 rows = 256 workgroups x 24
             }
             return gemv_rw<WT, 1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
@@ -616,6 +647,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.w2_h : (const void*)L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
+            if (c->batched && !c->batched_valu) return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st);   // 48 tiles x 4 K-ranges
             if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);
             return gemv_rw<WT, 4, PRO_NONE, EPI_RESID>(c->rw_fc2, a, B, I, st);
         }
@@ -1084,16 +1116,21 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
             if (e != hipSuccess) { if (tmp) hipFree(tmp); HIPRET(e); }
             a.xin = a.hout;
         }
+        const char* bv = getenv("ER_BATCHED_VALU");
+        const bool valu = bv && bv[0] == '1';
+        float* part = nullptr;
+        if (!valu) HIPCHK(hipMalloc(&part, (size_t)4 * NBM * n * 4));
         if (k == 1536) {
-            if (relu && !resid) e = gemv_batched_groups<float, 1, 2, EPI_RELU>(a, B, k, st);
-            else if (!relu && !resid) e = gemv_batched_groups<float, 1, 1, EPI_STORE>(a, B, k, st);
+            if (relu && !resid) e = valu ? gemv_batched_groups<float, 1, 2, EPI_RELU>(a, B, k, st) : gemv_mfma_groups<float, EPI_RELU>(a, B, k, part, st);
+            else if (!relu && !resid) e = gemv_batched_groups<float, 1, 1, EPI_STORE>(a, B, k, st);   // narrow: VALU kernel, as in the decode step
             else if (!relu && resid) e = gemv_batched_groups<float, 1, 1, EPI_RESID>(a, B, k, st);
             else e = hipErrorInvalidValue;
         } else if (k == 6144 && !relu && resid && !ln_w) {
-            e = gemv_batched_groups<float, 4, 1, EPI_RESID>(a, B, k, st);
+            e = valu ? gemv_batched_groups<float, 4, 1, EPI_RESID>(a, B, k, st) : gemv_mfma_groups<float, EPI_RESID>(a, B, k, part, st);
         } else {
             e = hipErrorInvalidValue;
         }
+        if (part) { hipStreamSynchronize(st); hipFree(part); }
         hipError_t e2 = hipStreamSynchronize(st);
         if (tmp) hipFree(tmp);
         HIPRET(e);

@@ -1,0 +1,140 @@
+// Batched decode projections on the fp32 matrix cores: out[b][n] = sum_k X[b][k] W[n][k] for up to 32 batch rows per
+// pass with the weights streamed ONCE (the VALU kernel in k_gemv.h needs one pass per 16 rows and is FMA-issue-bound
+// there: 32 rows x 28 M weights per layer is 1.8 GFLOP of scalar fmaf).  Same callers, prologue (prep_rows_kernel) and
+// epilogues as k_gemv.h; replaces the reference's nn.Linear calls at batch > 4
+// (core/transformer/modeling_opt.py:185,189-190,232,281,284,497).
+//
+// HBM-bound: v_mfma_f32_16x16x4_f32 with the 16 weight rows of a tile on the A side and 16 batch rows on the B side.
+// Lane (i = lane & 15, kq = lane >> 4) loads 16 bytes of weight row n0 + i - no LDS transpose is needed because the
+// matrix core sums over k in any order as long as A and B agree on which k sits in which (lane, element) slot:
+// element m of the lane's vector feeds MFMA number m, and the B operand of that MFMA is element m of the matching
+// 16-byte piece of X[b = lane & 15].  A workgroup = 16 waves = one 32-row tile x 16 K-slices of 96, every load issued
+// before the first MFMA; the 16 partial tiles meet in LDS and are added in slice order (deterministic, independent of
+// the other batch rows).  K = 6144 (fc2) is additionally split across workgroups (grid.y = 4); those partials go to
+// scratch and splitk_finish_kernel applies the epilogue.
+#pragma once
+#include "k_gemv.h"
+
+namespace er {
+
+typedef float gm_f4 __attribute__((ext_vector_type(4)));
+constexpr int GM_WAVES = 16, GM_THREADS = GM_WAVES * 64, GM_R2 = 2, GM_ROWS = 16 * GM_R2, GM_KW = 96;
+
+// A workgroup = 16 waves = a 32-row tile (two 16-row A tiles per wave, sharing the X registers: X comes from L2 once
+// per 32 weight rows) x 16 K-slices of 96 = K-range 1536.  NBH = 16-row batch halves (1 or 2); SPLIT: raw partials.
+template <typename WT, int NBH, int EPI, bool SPLIT>
+__global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int nb_valid, int K, float* part) {
+    constexpr int EPL = WTraits<WT>::EPL;            // weights per 16-byte load: 4 (fp32) or 8 (fp16)
+    constexpr int NLD = GM_KW / (4 * EPL);           // loads per lane and row tile: a wave-load covers 16 rows x 4*EPL k
+    constexpr int XV = EPL / 4;
+    __shared__ __attribute__((aligned(16))) float red[GM_WAVES][GM_R2 * NBH][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * GM_ROWS;
+    const int kbase = (blockIdx.y * GM_WAVES + wid) * GM_KW + kq * EPL;
+
+    f32x4 w[GM_R2][NLD];
+#pragma unroll
+    for (int t = 0; t < GM_R2; ++t) {
+        const WT* wp = reinterpret_cast<const WT*>(a.W) + (long long)min(n0 + 16 * t + li, a.N - 1) * K + kbase;
+#pragma unroll
+        for (int c = 0; c < NLD; ++c) w[t][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + c * 4 * EPL));
+    }
+    f32x4 x[NBH][NLD][XV];
+#pragma unroll
+    for (int h = 0; h < NBH; ++h) {
+        const float* xp = a.xin + (long long)min(h * 16 + li, nb_valid - 1) * K + kbase;
+#pragma unroll
+        for (int c = 0; c < NLD; ++c)
+#pragma unroll
+            for (int u = 0; u < XV; ++u) x[h][c][u] = *reinterpret_cast<const f32x4*>(xp + c * 4 * EPL + 4 * u);
+    }
+    // the output this thread finishes: slot = tid >> 8 = (row tile t, batch half h), lane image ol, register orr
+    //   n = n0 + 16*t + 4*(ol >> 4) + orr,  b = 16*h + (ol & 15)
+    const int slot = tid >> 8, ol = (tid >> 2) & 63, orr = tid & 3;
+    const int ot = slot / NBH, oh = slot - ot * NBH;
+    const int on = n0 + 16 * ot + 4 * (ol >> 4) + orr, ob = oh * 16 + (ol & 15);
+    const bool active = slot < GM_R2 * NBH && on < a.N && ob < nb_valid;
+    EpiPre pre{0.f, 0.f, 0};
+    if (!SPLIT && active) pre = gemv_epi_prefetch<EPI>(a, on, ob);
+
+    // keep every load above the first MFMA: without this the scheduler sinks the loads next to their uses to save
+    // registers, and a wave then has a few hundred bytes in flight instead of its whole slice
+    __builtin_amdgcn_sched_barrier(0);
+    gm_f4 acc[GM_R2][NBH];
+#pragma unroll
+    for (int t = 0; t < GM_R2; ++t)
+#pragma unroll
+        for (int h = 0; h < NBH; ++h) acc[t][h] = (gm_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NLD; ++c) {
+        float wf[GM_R2][EPL];
+#pragma unroll
+        for (int t = 0; t < GM_R2; ++t) {
+            if constexpr (sizeof(WT) == 4) {
+                wf[t][0] = w[t][c].x; wf[t][1] = w[t][c].y; wf[t][2] = w[t][c].z; wf[t][3] = w[t][c].w;
+            } else {
+                const f16x8 hv = __builtin_bit_cast(f16x8, w[t][c]);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) wf[t][m] = (float)hv[m];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < EPL; ++m)
+#pragma unroll
+            for (int t = 0; t < GM_R2; ++t)
+#pragma unroll
+                for (int h = 0; h < NBH; ++h)
+                    acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][m], x[h][c][m >> 2][m & 3], acc[t][h], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < GM_R2; ++t)
+#pragma unroll
+        for (int h = 0; h < NBH; ++h) *reinterpret_cast<gm_f4*>(&red[wid][t * NBH + h][lane][0]) = acc[t][h];
+    __syncthreads();
+    if (slot < GM_R2 * NBH) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < GM_WAVES; ++wv) s += red[wv][slot][ol][orr];
+        if (active) {
+            if (SPLIT) part[((long long)blockIdx.y * nb_valid + ob) * a.N + on] = s;
+            else gemv_epilogue<EPI>(a, on, ob, s, pre);
+        }
+    }
+}
+
+// out(b, n) = epilogue(sum_s part[s][b][n]) in slice order
+template <int EPI>
+__global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const float* part, int S, int nb_valid) {
+    const long long i = (long long)blockIdx.x * ER_WG + threadIdx.x;
+    if (i >= (long long)nb_valid * a.N) return;
+    const int b = (int)(i / a.N), n = (int)(i - (long long)b * a.N);
+    const EpiPre pre = gemv_epi_prefetch<EPI>(a, n, b);
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[((long long)k * nb_valid + b) * a.N + n];
+    gemv_epilogue<EPI>(a, n, b, s, pre);
+}
+
+// one pass over <= 32 rows; K = ksplit * 1536.  `part` must hold ksplit * nb_valid * N floats when ksplit > 1.
+template <typename WT, int EPI>
+inline hipError_t launch_gemv_mfma(const GemvArgs& a, int nb_valid, int K, float* part, hipStream_t st) {
+    const int ksplit = K / (GM_WAVES * GM_KW);
+    if (K != ksplit * GM_WAVES * GM_KW) return hipErrorInvalidValue;
+    const dim3 grid((a.N + GM_ROWS - 1) / GM_ROWS, ksplit);
+    const bool two = nb_valid > 16;
+    if (ksplit == 1) {
+        if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, false>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+        else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, false>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+        return hipGetLastError();
+    }
+    if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, true>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+    else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, true>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long long total = (long long)nb_valid * a.N;
+    hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3((unsigned)((total + ER_WG - 1) / ER_WG)), dim3(ER_WG), 0, st, a, part, ksplit,
+                       nb_valid);
+    return hipGetLastError();
+}
+
+}  // namespace er

@@ -68,24 +68,59 @@ def test_gemv_fc2_ksplit_resid(B):
     close(y, x.double() @ w.double().T + b.double() + r.double(), 4e-6, 1e-5, "fc2")
 
 
-@pytest.mark.parametrize("B", [5, 16, 19])
-def test_gemv_batched_rows_bit_identical_to_single(B):
-    """B > 4 takes the batched kernels (weights streamed once per 16 rows): every row must equal,
-    bit for bit, the same row pushed through the B = 1 kernel (same fmaf chains and reduction tree)."""
-    from edgerunner_amd import kernels as K
+def _batched_case(B):
     w1, b1 = rnd(6144, 1536, seed=60, scale=0.02), rnd(6144, seed=61, scale=0.02)
     w2, b2 = rnd(1536, 6144, seed=62, scale=0.02), rnd(1536, seed=63, scale=0.02)
     wh = rnd(518, 1536, seed=64, scale=0.02)
     x = rnd(B, 1536, seed=65) * 2 + 0.3
     lw, lb = 1 + 0.1 * rnd(1536, seed=66), 0.05 * rnd(1536, seed=67)
     r = rnd(B, 1536, seed=68)
+    return w1, b1, w2, b2, wh, x, lw, lb, r
+
+
+def _batched_run(c):
+    from edgerunner_amd import kernels as K
+    w1, b1, w2, b2, wh, x, lw, lb, r = c
     f, xn = K.gemv(w1, x, b1, lw, lb, relu=True, return_xnorm=True)          # fc1-like: LN + ReLU
     y = K.gemv(w2, f, b2, resid=r)                                             # fc2-like: K = 6144 + residual
     lg = K.gemv(wh, x, None, lw, lb)                                           # lm_head-like: ragged N
     o = K.gemv(w2[:, :1536].contiguous(), x, b2, resid=r)                      # out_proj-like
+    return f, xn, y, lg, o
+
+
+@pytest.mark.parametrize("B", [5, 16, 19, 32, 37])
+def test_gemv_batched_matrix_core_rows(B):
+    """B > 4: fc1 / qkv-shaped and fc2 projections take the matrix-core kernels (k_gemv_mfma.h: weights streamed once
+    per pass of 32 rows, split-K for fc2), the narrow out_proj / lm_head the VALU batched kernel: accuracy against
+    float64, and a row's result must not depend on which other rows share its pass (same bits whether it runs in a
+    5-row or a B-row batch, first or second pass)."""
+    c = _batched_case(B)
+    w1, b1, w2, b2, wh, x, lw, lb, r = c
+    f, xn, y, lg, o = _batched_run(c)
     xr = torch.nn.functional.layer_norm(x.double(), (1536,), lw.double(), lb.double(), 1e-5)
+    close(xn, xr, 2e-6, 2e-6, "LayerNorm rows")
     close(f, torch.relu(xr @ w1.double().T + b1.double()), 2e-6, 1e-5, "batched fc1")
     close(y, f.double() @ w2.double().T + b2.double() + r.double(), 4e-6, 1e-5, "batched fc2")
+    close(lg, xr @ wh.double().T, 2e-6, 1e-5, "batched lm_head")
+    close(o, x.double() @ w2[:, :1536].double().T + b2.double() + r.double(), 2e-6, 1e-5, "batched out_proj")
+    idx = [B - 1, 0, B // 2, 1, 2]                                             # 5 rows -> still the batched path
+    sub = (w1, b1, w2, b2, wh, x[idx].contiguous(), lw, lb, r[idx].contiguous())
+    f5, xn5, _, lg5, o5 = _batched_run(sub)
+    from edgerunner_amd import kernels as K
+    y5 = K.gemv(w2, f[idx].contiguous(), b2, resid=r[idx].contiguous())
+    for got, full, name in ((f5, f, "fc1"), (xn5, xn, "ln"), (y5, y, "fc2"), (lg5, lg, "head"), (o5, o, "out_proj")):
+        assert torch.equal(got, full[idx]), f"{name}: a row's bits depend on its batch neighbours"
+
+
+@pytest.mark.parametrize("B", [5, 19])
+def test_gemv_batched_valu_rows_bit_identical_to_single(B, monkeypatch):
+    """ER_BATCHED_VALU=1 keeps the older VALU batched kernels (one pass per 16 rows): every row equals, bit for
+    bit, the same row pushed through the B = 1 kernel (same fmaf chains and reduction tree)."""
+    from edgerunner_amd import kernels as K
+    monkeypatch.setenv("ER_BATCHED_VALU", "1")
+    c = _batched_case(B)
+    w1, b1, w2, b2, wh, x, lw, lb, r = c
+    f, xn, y, lg, o = _batched_run(c)
     for i in range(B):
         f1, xn1 = K.gemv(w1, x[i:i + 1].contiguous(), b1, lw, lb, relu=True, return_xnorm=True)
         assert torch.equal(xn1[0], xn[i]), f"LayerNorm row {i} differs from the fused prologue"
