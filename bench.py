@@ -34,10 +34,16 @@ LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "ou
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
 
 
-KIND_TO_KERNEL = {"qkv_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 3>", "attn_decode": "attn_decode_f32_kernel<96, 4>",
-                  "attn_combine": "attn_combine_f32_kernel<96, 4>", "out_proj_gemv": "gemv_f32_kernel<6, 1, 1, 1, 0, 2>",
-                  "fc1_gemv": "gemv_f32_kernel<6, 1, 1, 2, 1, 1>", "fc2_gemv": "gemv_f32_kernel<6, 4, 1, 2, 0, 2>",
-                  "lm_head_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 0>", "sample_head": "sample_head_kernel"}
+# kernel names as rocprofv3 reports them (scripts/pmc_summary.py::short); gemv_kernel<WT, KS, NB, RW, PRO, EPI>
+KIND_TO_KERNEL = {"qkv_gemv": "gemv_kernel<float, 1, 1, 1, 1, 3>", "attn_decode": "attn_decode_kernel<float, 96, 4>",
+                  "attn_combine": "attn_combine_kernel<96>", "out_proj_gemv": "gemv_kernel<float, 1, 1, 1, 0, 2>",
+                  "fc1_gemv": "gemv_kernel<float, 1, 1, 2, 1, 1>", "fc2_gemv": "gemv_kernel<float, 4, 1, 2, 0, 2>",
+                  "lm_head_gemv": "gemv_kernel<float, 1, 1, 1, 1, 0>", "sample_head": "sample_head_kernel"}
+# the same kernels under the names of the first PMC pass of this round (before the fp16 templates were added)
+KIND_TO_KERNEL_OLD = {"qkv_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 3>", "attn_decode": "attn_decode_f32_kernel<96, 4>",
+                      "attn_combine": "attn_combine_f32_kernel<96, 4>", "out_proj_gemv": "gemv_f32_kernel<6, 1, 1, 1, 0, 2>",
+                      "fc1_gemv": "gemv_f32_kernel<6, 1, 1, 2, 1, 1>", "fc2_gemv": "gemv_f32_kernel<6, 4, 1, 2, 0, 2>",
+                      "lm_head_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 0>", "sample_head": "sample_head_kernel"}
 
 
 def pmc_traffic(kind):
@@ -46,7 +52,8 @@ def pmc_traffic(kind):
     separate --pmc runs, see scripts/gpu_pmc.sh).  Counters cannot be read inside the timed process."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_summary.json")
     try:
-        k = json.load(open(path))["kernels"][KIND_TO_KERNEL[kind]]
+        ks = json.load(open(path))["kernels"]
+        k = ks.get(KIND_TO_KERNEL[kind]) or ks[KIND_TO_KERNEL_OLD[kind]]
         note = " (attention measured at context 2050..2062: 2*L*1536*4 B algorithmic there)" if kind == "attn_decode" else ""
         return {"bytes": round(k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)),
                 "source": "profiles/r01_pmc_hbm_summary.json" + note}

@@ -16,9 +16,9 @@ from collections import defaultdict
 
 
 def short(name):
-    name = re.sub(r"\(.*$", "", name)
-    m = re.search(r"(gemv_f32_kernel<[^>]*>|attn_decode_f32_kernel<[^>]*>|attn_combine_f32_kernel<[^>]*>|[A-Za-z_0-9]+_kernel)", name)
-    return m.group(1) if m else name[:80]
+    """'void er::gemv_kernel<float, 1, 1, 2, 1, 1>(er::GemvArgs)' -> 'gemv_kernel<float, 1, 1, 2, 1, 1>'."""
+    m = re.search(r"(?:er::)?([A-Za-z_0-9]+(?:<[^()]*>)?)\s*\(", name)
+    return m.group(1) if m else re.sub(r"\(.*$", "", name)[:80]
 
 
 def stats(path):
