@@ -397,8 +397,8 @@ extern "C" int er_dit_forward(er_dit_ctx* c, const float* x, const float* cond, 
 }
 
 extern "C" int er_dit_sample(er_dit_ctx* c, const float* cond, int B, int M, float* latents, int steps, float guidance,
-                             void* stream) {
-    if (!c || !cond || !latents || B <= 0 || M <= 0 || steps <= 0 || steps > 1000)
+                             int init_step, void* stream) {
+    if (!c || !cond || !latents || B <= 0 || M <= 0 || steps <= 0 || steps > 1000 || init_step < 0 || init_step >= steps)
         return fail(ER_ERR_INVALID, "er_dit_sample: bad argument");
     ERCHK(er_dit_finalize_weights(c));
     HIPCHK(hipSetDevice(c->device));
@@ -431,7 +431,7 @@ extern "C" int er_dit_sample(er_dit_ctx* c, const float* cond, int B, int M, flo
     ERCHK(ensure(c->pred, 2 * nlat));
     ERCHK(ensure(c->t_dev, (size_t)2 * B));
     std::vector<float> th(2 * B);
-    for (int i = steps - 1; i >= 0; --i) {
+    for (int i = steps - 1 - init_step; i >= 0; --i) {     // scheduler.timesteps[init_step:]          models_dit.py:213
         const int t = i * ratio + 1;
         for (int b = 0; b < 2 * B; ++b) th[b] = (float)t;
         HIPCHK(hipMemcpyAsync(c->t_dev.p, th.data(), 2 * B * sizeof(float), hipMemcpyHostToDevice, st));

@@ -5,8 +5,8 @@ classifier-free guidance -> latents ``[B, 2048, 64]`` that ``LMM.generate`` cons
 
 Built: the CLIP ViT-H/14 image encoder (``image_encoder.vision_model.*``; architecture only - its pretrained
 weights cannot be fetched here, so parity runs use synthetic weights), ``proj_cond``/``norm_cond``,
-``DiT.forward``, ``run`` (latents=None).  Out of scope: training ``forward``, the img2img branch (``latents`` given),
-background removal / recentering of the input photo (rembg, kiui: infer_dit.py:83-96).
+``DiT.forward``, ``run`` (from noise, and the img2img branch with ``latents`` / ``strength``; ``num_repeat``).
+Out of scope: training ``forward``, background removal / recentering of the input photo (rembg, kiui: infer_dit.py:83-96).
 """
 from __future__ import annotations
 
@@ -18,6 +18,12 @@ import torch
 from . import native
 
 CLIP_DIM = 1280   # laion/CLIP-ViT-H-14 hidden width (core/models_dit.py:56)
+
+
+def ddim_alphas_cumprod(num_train: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012) -> torch.Tensor:
+    """alphas_cumprod of the reference's DDIMScheduler (core/models_dit.py:79-98: scaled_linear betas 0.00085..0.012, fp32)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
 
 
 class MDiT:
@@ -132,19 +138,35 @@ class MDiT:
     @torch.no_grad()
     def run(self, inputs, num_inference_steps=100, guidance_scale=7.5, num_repeat=1, latents=None, strength=0.5,
             noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """core/models_dit.py:184-229.  ``noise``: the initial Gaussian latents (default: torch.randn on the
-        device, like the reference); pass it explicitly to reproduce a CPU run."""
-        if latents is not None:
-            raise NotImplementedError("img2img branch (latents given) is not built")
+        """core/models_dit.py:184-229.  ``noise``: the Gaussian draw the reference takes from torch.randn /
+        torch.randn_like (default: drawn on the device, like the reference); pass it explicitly to reproduce a CPU
+        run.  ``latents`` given: the img2img branch (:207-209) - noise is added at timesteps[int(steps * strength)]
+        and the loop starts there."""
         cond = self.get_cond(inputs)
         cond = cond.repeat_interleave(num_repeat, dim=0).contiguous()
         B = cond.shape[0]
+        shape = (B, self.opt.point_latent_size, self.opt.point_latent_dim)
         if noise is None:
-            noise = torch.randn(B, self.opt.point_latent_size, self.opt.point_latent_dim, device=self.device, dtype=torch.float32)
-        lat = noise.to(self.device, torch.float32).contiguous().clone()
+            noise = torch.randn(*shape, device=self.device, dtype=torch.float32)
+        noise = noise.to(self.device, torch.float32)
+        steps = int(num_inference_steps)
+        if latents is None:
+            init_step = 0
+            lat = noise.contiguous().clone()
+        else:
+            init_step = int(steps * strength)
+            if not 0 <= init_step < steps:
+                raise IndexError(f"strength {strength} selects timestep index {init_step} of {steps}")   # timesteps[init_step]
+            latents = latents.to(self.device, torch.float32)
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"latents must be {shape}, got {tuple(latents.shape)}")
+            # DDIMScheduler.add_noise at t = timesteps[init_step] (leading spacing, steps_offset 1)
+            t = (steps - 1 - init_step) * (1000 // steps) + 1
+            a_t = ddim_alphas_cumprod()[t].item()
+            lat = ((a_t ** 0.5) * latents + ((1.0 - a_t) ** 0.5) * noise).contiguous()
         self._sync_in()
         with torch.cuda.stream(self.stream):
-            native.check(self.lib.er_dit_sample(self._ctx, native.ptr(cond), B, cond.shape[1], native.ptr(lat),
-                                                int(num_inference_steps), float(guidance_scale), self._sp()), "er_dit_sample")
+            native.check(self.lib.er_dit_sample(self._ctx, native.ptr(cond), B, cond.shape[1], native.ptr(lat), steps,
+                                                float(guidance_scale), init_step, self._sp()), "er_dit_sample")
         self._sync_out()
         return lat

@@ -95,7 +95,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.er_dit_project_cond.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.er_dit_encode_image.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     lib.er_dit_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_float), ci, ci, vp, vp]
-    lib.er_dit_sample.argtypes = [vp, vp, ci, ci, vp, ci, cf, vp]
+    lib.er_dit_sample.argtypes = [vp, vp, ci, ci, vp, ci, cf, ci, vp]
     lib.er_k_gemv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
     lib.er_k_attn_decode.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), vp, ci, ci, ci, ci, ci, ci, vp]
     lib.er_k_gemm.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp]

@@ -183,11 +183,13 @@ int er_dit_encode_image(er_dit_ctx* ctx, const float* images_dev, int batch, int
 /* DiT.forward(x, c, t)   core/transformer/dit.py:168-196: x float[B,N,latent_dim], c float[B,M,hidden], t_host float[B] */
 int er_dit_forward(er_dit_ctx* ctx, const float* x_dev, const float* c_dev, const float* t_host, int batch,
                    int m_tokens, float* out_dev, void* stream);
-/* MDiT.run's denoise loop (core/models_dit.py:184-229, num_repeat = 1): DDIM (v-prediction, scaled-linear betas
- * 0.00085..0.012, leading spacing, steps_offset 1, eta 0) with classifier-free guidance over [zeros | cond];
- * latents_dev float[B, N, latent_dim] holds the initial Gaussian noise on entry and the result on exit. */
+/* MDiT.run's denoise loop (core/models_dit.py:184-229; num_repeat is a repeat_interleave of cond on the caller's
+ * side): DDIM (v-prediction, scaled-linear betas 0.00085..0.012, leading spacing, steps_offset 1, eta 0) with
+ * classifier-free guidance over [zeros | cond], over scheduler.timesteps[init_step:] (init_step = 0: from pure
+ * noise; > 0: the img2img branch, :207-209, the caller has already added noise at timesteps[init_step]).
+ * latents_dev float[B, N, latent_dim] holds the starting latents on entry and the result on exit. */
 int er_dit_sample(er_dit_ctx* ctx, const float* cond_dev, int batch, int m_tokens, float* latents_dev,
-                  int num_inference_steps, float guidance_scale, void* stream);
+                  int num_inference_steps, float guidance_scale, int init_step, void* stream);
 
 /* ---- measurement ---- */
 #define ER_NUM_KERNEL_KINDS 8

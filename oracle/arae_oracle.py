@@ -490,16 +490,24 @@ def dit_project_cond(sd: StateDict, clip_hidden):
 
 @torch.no_grad()
 def mdit_run(sd: StateDict, cond, init_latents, num_heads: int, num_inference_steps=100, guidance_scale=7.5,
-             forward_fn=None):
-    """MDiT.run (core/models_dit.py:184-229) from projected cond [B,M,C] and the initial noise the reference
-    draws with torch.randn (passed in, RNG streams do not transfer across devices); num_repeat = 1."""
+             forward_fn=None, latents=None, strength=0.5):
+    """MDiT.run (core/models_dit.py:184-229) from projected cond [B,M,C] and the Gaussian draw the reference takes
+    from torch.randn / randn_like (`init_latents`, passed in: RNG streams do not transfer across devices);
+    num_repeat = 1.  `latents` given: the img2img branch (:207-209), DDIMScheduler.add_noise at
+    timesteps[int(steps * strength)] and the loop over timesteps[init_step:]."""
     fwd = forward_fn or (lambda x, c, t: dit_forward(sd, x, c, t, num_heads))
     ts, ac, final = ddim_schedule(num_inference_steps)
     ratio = 1000 // num_inference_steps
     B = cond.shape[0]
-    latents = init_latents.clone()
+    if latents is None:
+        init_step = 0
+        latents = init_latents.clone()
+    else:
+        init_step = int(num_inference_steps * strength)
+        a_t = ac[ts[init_step]]
+        latents = (a_t ** 0.5) * latents + ((1 - a_t) ** 0.5) * init_latents        # scheduler.add_noise
     c2 = torch.cat([torch.zeros_like(cond), cond], dim=0)
-    for t in ts:
+    for t in ts[init_step:]:
         x2 = torch.cat([latents] * 2, dim=0)
         t_in = torch.tensor([t] * B * 2, dtype=latents.dtype)
         pred = fwd(x2, c2, t_in)

@@ -123,8 +123,30 @@ def test_unbuilt_pieces_fail_loudly(setup):
     opt, sd, m, g, clip_hidden, noise, x = setup
     with pytest.raises(NotImplementedError, match="image encoder"):
         m.get_cond(torch.rand(1, 3, 512, 512))
-    with pytest.raises(NotImplementedError):
-        m.run(clip_hidden.to(DEV), latents=noise.to(DEV))
+    with pytest.raises(IndexError):                     # reference: scheduler.timesteps[int(steps * strength)] out of range
+        m.run(clip_hidden.to(DEV), num_inference_steps=4, latents=noise.to(DEV), strength=1.0)
+    with pytest.raises(ValueError, match="latents must be"):
+        m.run(clip_hidden.to(DEV), num_inference_steps=4, latents=noise[:, :100].to(DEV))
+
+
+def test_img2img_branch_and_num_repeat(setup):
+    """MDiT.run with latents given (core/models_dit.py:207-209: add_noise at timesteps[int(steps * strength)], loop
+    over the remaining timesteps) and num_repeat = 2 (cond repeat_interleave, :203), vs the oracle."""
+    import arae_oracle as O
+    opt, sd, m, g, clip_hidden, noise, x = setup
+    gen = torch.Generator().manual_seed(123)
+    ch = torch.randn(1, 257, 1280, generator=gen)
+    nz = torch.randn(2, 2048, 64, generator=gen)
+    lat0 = 0.5 * torch.randn(2, 2048, 64, generator=gen)
+    cond2 = O.dit_project_cond(sd, ch).repeat_interleave(2, dim=0)
+    for strength, steps in ((0.5, 6), (0.0, 3)):
+        want = O.mdit_run(sd, cond2, nz, opt.dit_num_heads, num_inference_steps=steps, guidance_scale=3.0, latents=lat0,
+                          strength=strength)
+        got = m.run(ch.to(DEV), num_inference_steps=steps, guidance_scale=3.0, num_repeat=2, latents=lat0.to(DEV),
+                    strength=strength, noise=nz.to(DEV)).cpu()
+        err = float((got - want).abs().max())
+        print(f"img2img strength {strength}, {steps} steps, num_repeat 2: max abs err {err:.3e}")
+        assert err < 2e-3
 
 
 def test_fast_mode_fp16_mfma_vs_emulation(setup):
