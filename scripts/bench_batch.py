@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Aggregate decode throughput at batch B (independent clouds, greedy, EOS suppressed) on one GPU.
-BASELINE configs[2]/[3] shapes: B=32, T=4*num_face.  Usage: bench_batch.py B[,B..] T [num_face] [fp32|fp16]"""
+BASELINE configs[2]/[3] shapes: B=32, T=4*num_face.  Usage: bench_batch.py B[,B..] T [num_face] [fp32|fp16] [greedy|sample]
+(configs[2] = `bench_batch.py 32 16000 4000 fp16 sample`; four rows are checked against the LR_ABSCO grammar)."""
 import dataclasses
 import json
 import os
@@ -21,8 +22,9 @@ def main():
     T = int(sys.argv[2])
     nf = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     precision = sys.argv[4] if len(sys.argv) > 4 else "fp32"
+    mode = sys.argv[5] if len(sys.argv) > 5 else "greedy"
     esz = 4 if precision == "fp32" else 2
-    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=24, generate_mode="greedy")
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=24, generate_mode=mode)
     lmm = LMM(opt, "cuda:0", precision=precision)
     lmm.mesh_decoder.load_state_iter(W.iter_state_dict(opt, 0, "perturbed"), strict=True)
     for B in Bs:
@@ -34,7 +36,15 @@ def main():
         ms = lmm.mesh_decoder.last_decode_ms
         mean_L = 2050 + (T - 1) / 2
         bytes_step = 680_752_128 * esz + B * 73_728 * (mean_L + 1) * esz
-        print(json.dumps({"precision": precision, "B": B, "T": T, "decode_ms": round(ms, 1), "ms_per_step": round(ms / T, 3),
+        from edgerunner_amd.grammar import GrammarState
+        from edgerunner_amd import native
+        for r in sorted({0, B // 4, B // 2, B - 1}):         # sampled rows must be legal LR_ABSCO sentences without EOS
+            st, last = GrammarState(native.ER_GRAMMAR_LR_ABSCO, 518), None
+            for t in toks[r].tolist():
+                assert t in st.allowed(last) and t != 2, (r, t)
+                last = t
+        distinct = len({tuple(t[:256]) for t in toks})
+        print(json.dumps({"precision": precision, "mode": mode, "B": B, "T": T, "distinct_rows": distinct, "decode_ms": round(ms, 1), "ms_per_step": round(ms / T, 3),
                           "aggregate_tok_s": round(B * T / ms * 1e3, 1), "end_to_end_tok_s": round(B * T / wall, 1),
                           "algorithmic_GBps": round(bytes_step / (ms / T * 1e-3) / 1e9, 1),
                           }), flush=True)
