@@ -54,6 +54,7 @@ struct LayerW {
     // fast mode (fp16 storage): *_h hold the streamed fp16 matrices; the fp32 copies then hold the SAME
     // fp16-rounded values (used by the prefill GEMMs), so prefill and decode see one model
     _Float16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;
+    void *wqkv_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;   // tiled copies for the matrix-core batched kernels (k_gemv_mfma.h)
     float *wqkv = nullptr, *bqkv = nullptr;   // fused [3*hidden][hidden] in q,k,v order
     float *wo = nullptr, *bo = nullptr, *ln1w = nullptr, *ln1b = nullptr;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *ln2w = nullptr, *ln2b = nullptr;
@@ -106,7 +107,8 @@ struct er_ctx {
     bool use_graph = true;
     bool batched = false;     // B > 4 (or ER_FORCE_BATCHED=1): weights streamed once per pass of 32 rows (matrix cores)
     bool batched_valu = false;   // ER_BATCHED_VALU=1: the older VALU kernels (one pass per 16 rows), kept for A/B runs
-    float* skpart = nullptr;  // split-K partials of the batched out_proj / fc2 / lm_head
+    float* skpart = nullptr;  // split-K partials of the batched fc2
+    bool tiled_valid = false; // LayerW::*_t match the loaded weights
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
@@ -299,6 +301,7 @@ extern "C" int er_load_tensor(er_ctx* c, const char* key_c, const void* data, in
     const std::string key(key_c);
     auto it = c->need.find(key);
     if (it == c->need.end()) return 1;   // strict=False: unknown keys are ignored
+    c->tiled_valid = false;              // any reload invalidates the tiled copies of the batched path
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
     const er_config& g = c->cfg;
@@ -421,6 +424,40 @@ extern "C" int er_finalize_weights(er_ctx* c) {
     return ER_OK;
 }
 
+// second copy of the qkv / fc1 / fc2 matrices in the layout the matrix-core batched kernels stream (made the first
+// time a batch > 4 is reserved: 2.5 GB fp32 / 1.3 GB fp16 of the 288 GB)
+template <typename WT>
+static int make_tiled(er_ctx* c, const void* src, void** dst, int N, int K) {
+    if (!*dst) {
+        HIPCHK(hipMalloc(dst, tiled_weight_bytes<WT>(N, K)));
+        c->owned.push_back(*dst);
+    }
+    hipLaunchKernelGGL((tile_weights_kernel<WT>), dim3(2048), dim3(ER_WG), 0, c->own_stream, reinterpret_cast<const WT*>(src),
+                       reinterpret_cast<f32x4*>(*dst), N, K);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int make_tiled_weights(er_ctx* c) {
+    if (c->tiled_valid) return 0;
+    for (auto& kv : c->need)
+        if (!kv.second) return 0;          // weights still loading: er_prefill comes back here
+    const int H = c->cfg.hidden_dim, I = c->cfg.intermediate_dim;
+    for (LayerW& L : c->layers) {
+        if (c->fast) {
+            ERCHK(make_tiled<_Float16>(c, L.wqkv_h, &L.wqkv_t, 3 * H, H));
+            ERCHK(make_tiled<_Float16>(c, L.w1_h, &L.w1_t, I, H));
+            ERCHK(make_tiled<_Float16>(c, L.w2_h, &L.w2_t, H, I));
+        } else {
+            ERCHK(make_tiled<float>(c, L.wqkv, &L.wqkv_t, 3 * H, H));
+            ERCHK(make_tiled<float>(c, L.w1, &L.w1_t, I, H));
+            ERCHK(make_tiled<float>(c, L.w2, &L.w2_t, H, I));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->own_stream));
+    c->tiled_valid = true;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ KV cache / workspace
 extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     if (!c || batch <= 0 || max_len <= 0) return fail(ER_ERR_INVALID, "er_kv_reserve: bad argument");
@@ -466,6 +503,7 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     c->batched = batch > 4 || (fb && fb[0] == '1');
     const char* bv = getenv("ER_BATCHED_VALU");
     c->batched_valu = bv && bv[0] == '1';
+    if (c->batched && !c->batched_valu) ERCHK(make_tiled_weights(c));
     return ER_OK;
 }
 
@@ -616,7 +654,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->hbuf;
-                if (!c->batched_valu) return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, c->skpart, st);   // 144 tiles of 32 rows
+                if (!c->batched_valu) { a.W = L.wqkv_t; return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, c->skpart, st); }   // 144 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_QKV>(a, B, H, st);   // 4608 rows = 192 workgroups x 24: one round
             }
             if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
@@ -639,7 +677,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->h1buf;
-                if (!c->batched_valu) return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, c->skpart, st);   // 192 tiles of 32 rows
+                if (!c->batched_valu) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, c->skpart, st); }   // 192 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_RELU>(a, B, H, st);   // 6144 rows = 256 workgroups x 24
             }
             return gemv_rw<WT, 1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
@@ -647,7 +685,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.w2_h : (const void*)L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
-            if (c->batched && !c->batched_valu) return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st);   // 48 tiles x 4 K-ranges
+            if (c->batched && !c->batched_valu) { a.W = L.w2_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st); }   // 48 tiles x 4 K-ranges
             if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);
             return gemv_rw<WT, 4, PRO_NONE, EPI_RESID>(c->rw_fc2, a, B, I, st);
         }
@@ -832,6 +870,7 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
     if (c->B != B) return fail(ER_ERR_INVALID, "er_prefill: batch %d but KV cache reserved for %d (call er_kv_reserve)", B, c->B);
     if (S >= c->Lcap) return fail(ER_ERR_CAPACITY, "prefix length %d does not fit the reserved KV cache (%d)", S, c->Lcap);
     HIPCHK(hipSetDevice(c->device));
+    if (c->batched && !c->batched_valu) ERCHK(make_tiled_weights(c));
     hipStream_t st = pick(c, stream);
     const er_config& g = c->cfg;
     const int H = g.hidden_dim, I = g.intermediate_dim, NH = g.num_heads, D = c->D;
@@ -1119,17 +1158,26 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
         const char* bv = getenv("ER_BATCHED_VALU");
         const bool valu = bv && bv[0] == '1';
         float* part = nullptr;
-        if (!valu) HIPCHK(hipMalloc(&part, (size_t)4 * NBM * n * 4));
+        void* wt = nullptr;              // tiled copy of w for the matrix-core kernels (the decode step keeps one per matrix)
+        const bool mfma = !valu && ((k == 1536 && relu && !resid) || (k == 6144 && !relu && resid && !ln_w));
+        if (mfma) {
+            HIPCHK(hipMalloc(&part, (size_t)4 * NBM * n * 4));
+            HIPCHK(hipMalloc(&wt, tiled_weight_bytes<float>(n, k)));
+            hipLaunchKernelGGL((tile_weights_kernel<float>), dim3(1024), dim3(ER_WG), 0, st, w, reinterpret_cast<f32x4*>(wt), n, k);
+        }
+        GemvArgs am = a;
+        am.W = wt;
         if (k == 1536) {
-            if (relu && !resid) e = valu ? gemv_batched_groups<float, 1, 2, EPI_RELU>(a, B, k, st) : gemv_mfma_groups<float, EPI_RELU>(a, B, k, part, st);
+            if (relu && !resid) e = valu ? gemv_batched_groups<float, 1, 2, EPI_RELU>(a, B, k, st) : gemv_mfma_groups<float, EPI_RELU>(am, B, k, part, st);
             else if (!relu && !resid) e = gemv_batched_groups<float, 1, 1, EPI_STORE>(a, B, k, st);   // narrow: VALU kernel, as in the decode step
             else if (!relu && resid) e = gemv_batched_groups<float, 1, 1, EPI_RESID>(a, B, k, st);
             else e = hipErrorInvalidValue;
         } else if (k == 6144 && !relu && resid && !ln_w) {
-            e = valu ? gemv_batched_groups<float, 4, 1, EPI_RESID>(a, B, k, st) : gemv_mfma_groups<float, EPI_RESID>(a, B, k, part, st);
+            e = valu ? gemv_batched_groups<float, 4, 1, EPI_RESID>(a, B, k, st) : gemv_mfma_groups<float, EPI_RESID>(am, B, k, part, st);
         } else {
             e = hipErrorInvalidValue;
         }
+        if (wt) { hipStreamSynchronize(st); hipFree(wt); }
         if (part) { hipStreamSynchronize(st); hipFree(part); }
         hipError_t e2 = hipStreamSynchronize(st);
         if (tmp) hipFree(tmp);

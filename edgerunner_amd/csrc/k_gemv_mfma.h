@@ -4,6 +4,11 @@
 // epilogues as k_gemv.h; replaces the reference's nn.Linear calls at batch > 4
 // (core/transformer/modeling_opt.py:185,189-190,232,281,284,497).
 //
+// Weight layout: the kernel streams a TILED copy of the matrix (tile_weights_kernel, made once when a batch > 4 is first
+// reserved): [N/16][K/(4*EPL)] tiles of 1 KiB, inside a tile piece number (kq*16 + i) = the lane that consumes it, so a
+// wave-load is one contiguous 1 KiB line group and a wave's whole slice is 6 (fp16: 3) consecutive KiB.  Reading the
+// row-major matrix with lane = row (16 rows x 64 B, 6 KiB apart, per instruction) ran at a third of the speed.
+//
 // HBM-bound: v_mfma_f32_16x16x4_f32 with the 16 weight rows of a tile on the A side and 16 batch rows on the B side.
 // Lane (i = lane & 15, kq = lane >> 4) loads 16 bytes of weight row n0 + i - no LDS transpose is needed because the
 // matrix core sums over k in any order as long as A and B agree on which k sits in which (lane, element) slot:
@@ -33,13 +38,8 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     const int n0 = blockIdx.x * GM_ROWS;
     const int kbase = (blockIdx.y * GM_WAVES + wid) * GM_KW + kq * EPL;
 
-    f32x4 w[GM_R2][NLD];
-#pragma unroll
-    for (int t = 0; t < GM_R2; ++t) {
-        const WT* wp = reinterpret_cast<const WT*>(a.W) + (long long)min(n0 + 16 * t + li, a.N - 1) * K + kbase;
-#pragma unroll
-        for (int c = 0; c < NLD; ++c) w[t][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + c * 4 * EPL));
-    }
+    // issue order = arrival order (vmcnt is in-order): first X (L2-resident, back within a microsecond), then the weights
+    // chunk by chunk, so the MFMAs of chunk c start as soon as that chunk lands while the later chunks still stream
     f32x4 x[NBH][NLD][XV];
 #pragma unroll
     for (int h = 0; h < NBH; ++h) {
@@ -49,6 +49,16 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
 #pragma unroll
             for (int u = 0; u < XV; ++u) x[h][c][u] = *reinterpret_cast<const f32x4*>(xp + c * 4 * EPL + 4 * u);
     }
+    f32x4 w[GM_R2][NLD];
+    const f32x4* wp[GM_R2];
+    const int KT = K / (4 * EPL), kt0 = (blockIdx.y * GM_WAVES + wid) * NLD, NT = (a.N + 15) / 16;
+#pragma unroll
+    for (int t = 0; t < GM_R2; ++t)     // tile (nt, kt) starts at piece (nt*KT + kt)*64; this lane's piece is number `lane`
+        wp[t] = reinterpret_cast<const f32x4*>(a.W) + ((long long)min(n0 / 16 + t, NT - 1) * KT + kt0) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < NLD; ++c)
+#pragma unroll
+        for (int t = 0; t < GM_R2; ++t) w[t][c] = __builtin_nontemporal_load(wp[t] + c * 64);
     // the output this thread finishes: slot = tid >> 8 = (row tile t, batch half h), lane image ol, register orr
     //   n = n0 + 16*t + 4*(ol >> 4) + orr,  b = 16*h + (ol & 15)
     const int slot = tid >> 8, ol = (tid >> 2) & 63, orr = tid & 3;
@@ -103,6 +113,25 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     }
 }
 
+// row-major [N][K] -> the tiled layout above; N is padded to a multiple of 16 with zero rows
+template <typename WT>
+__global__ __launch_bounds__(ER_WG) void tile_weights_kernel(const WT* src, f32x4* dst, int N, int K) {
+    constexpr int EPL = WTraits<WT>::EPL;
+    const int KT = K / (4 * EPL), NT = (N + 15) / 16;
+    const long long total = (long long)NT * KT * 64;
+    for (long long p = (long long)blockIdx.x * ER_WG + threadIdx.x; p < total; p += (long long)gridDim.x * ER_WG) {
+        const int lane = (int)(p & 63);
+        const long long tile = p >> 6;
+        const int nt = (int)(tile / KT), kt = (int)(tile - (long long)nt * KT);
+        const int n = nt * 16 + (lane & 15), k = kt * 4 * EPL + (lane >> 4) * EPL;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < N) v = *reinterpret_cast<const f32x4*>(src + (long long)n * K + k);
+        dst[p] = v;
+    }
+}
+template <typename WT>
+inline size_t tiled_weight_bytes(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K * sizeof(WT); }
+
 // out(b, n) = epilogue(sum_s part[s][b][n]) in slice order
 template <int EPI>
 __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const float* part, int S, int nb_valid) {
@@ -115,7 +144,7 @@ __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const 
     gemv_epilogue<EPI>(a, n, b, s, pre);
 }
 
-// one pass over <= 32 rows; K = ksplit * 1536.  `part` must hold ksplit * nb_valid * N floats when ksplit > 1.
+// one pass over <= 32 rows; K = ksplit * 1536; a.W must point at the TILED copy of the matrix.  `part` must hold ksplit * nb_valid * N floats when ksplit > 1.
 template <typename WT, int EPI>
 inline hipError_t launch_gemv_mfma(const GemvArgs& a, int nb_valid, int K, float* part, hipStream_t st) {
     const int ksplit = K / (GM_WAVES * GM_KW);
