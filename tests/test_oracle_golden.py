@@ -103,3 +103,66 @@ def test_full_golden_is_well_formed(gold_full, manifest):
             assert int(torch.argmax(s + mask)) == ids[t], t
         assert ids[t] in allowed
         hist = torch.cat([hist, torch.tensor([ids[t]])])
+
+
+# ------------------------------------------------------------------ DiT / CLIP front-end (scope row f3)
+@pytest.fixture(scope="module")
+def gold_dit():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dit_small.npz")))
+
+
+def test_dit_forward_and_sampler_vs_reference_module_golden(gold_dit):
+    """oracle dit_forward / mdit_run against rows the reference's own DiT module produced (oracle/make_golden.py dit;
+    bit-identical there).  The 6-step sampler costs ~12 DiT forwards of 2 layers on the CPU."""
+    g = gold_dit
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=2, generate_mode="greedy", cond_mode="point_latent",
+                              dit_num_layers=2)
+    sd = W.make_dit_state_dict(opt, 0, "perturbed")
+    gen = torch.Generator().manual_seed(int(g["seed"][0]))
+    clip_hidden = torch.randn(1, 257, 1280, generator=gen)
+    noise = torch.randn(1, 2048, 64, generator=gen)
+    x = torch.randn(2, 2048, 64, generator=gen)
+    cond = O.dit_project_cond(sd, clip_hidden)
+    assert np.abs(cond[0, [0, 100, 256]].numpy() - g["cond_rows"]).max() < 1e-5
+    c2 = torch.cat([torch.zeros_like(cond), cond])
+    y = O.dit_forward(sd, x, c2, torch.tensor(g["t"]), opt.dit_num_heads)
+    rows = g["rows"].tolist()
+    assert np.abs(y[:, rows].numpy() - g["fwd_rows"]).max() < 1e-4
+    assert abs(float(y.double().sum()) - g["fwd_sum"][0]) / g["fwd_sum"][1] < 1e-6
+    lat = O.mdit_run(sd, cond, noise, opt.dit_num_heads, num_inference_steps=6, guidance_scale=7.5)
+    assert np.abs(lat[0, rows].numpy() - g["lat_rows"]).max() < 5e-4
+    assert abs(float(lat.double().sum()) - g["lat_sum"][0]) / g["lat_sum"][1] < 1e-5
+
+
+def test_clip_restatement_vs_installed_transformers_golden(gold_dit):
+    """oracle clip_vision_forward (transformers 4.46.2 CLIPVisionModel restated at state_dict level) against rows the
+    installed transformers' CLIPVisionModel produced on the same synthetic weights."""
+    g = gold_dit
+    gen = torch.Generator().manual_seed(int(g["image_seed_note"][0]))
+    for shape in ((1, 257, 1280), (1, 2048, 64), (2, 2048, 64)):     # img is the 4th draw of this generator
+        torch.randn(*shape, generator=gen)
+    img = torch.rand(1, 3, 512, 512, generator=gen)
+    hid = O.clip_vision_forward(W.make_clip_state_dict(2, 0, "perturbed"), O.clip_preprocess(img))
+    assert hid.shape == (1, 257, 1280)
+    assert np.abs(hid[0, [0, 1, 128, 256]].numpy() - g["clip_rows"]).max() < 1e-4
+    assert abs(float(hid.double().sum()) - g["clip_sum"][0]) / g["clip_sum"][1] < 1e-5
+
+
+def test_ddim_schedule_and_img2img_noise_level():
+    """The restated diffusers DDIMScheduler tables (leading spacing, steps_offset 1, scaled-linear betas in fp32) and the
+    product's copy of alphas_cumprod used by MDiT.run's img2img branch."""
+    from edgerunner_amd.models_dit import ddim_alphas_cumprod
+    ts, ac, final = O.ddim_schedule(100)
+    assert ts[0] == 991 and ts[-1] == 1 and len(ts) == 100 and all(a - b == 10 for a, b in zip(ts, ts[1:]))
+    assert torch.equal(ddim_alphas_cumprod(), ac) and final == ac[0]
+    assert abs(float(ac[0]) - (1 - 0.00085)) < 1e-6 and 0.004 < float(ac[-1]) < 0.005
+    ts6, _, _ = O.ddim_schedule(6)
+    assert ts6 == [831, 665, 499, 333, 167, 1]
+    # v-prediction step at the last timestep lands on final_alpha_cumprod = alphas_cumprod[0] (set_alpha_to_one=False)
+    s, v = torch.randn(4), torch.randn(4)
+    out = O.ddim_step_v(s, v, 1, ac, final, 10)
+    a_t, a_p = ac[1], ac[0]
+    x0 = a_t.sqrt() * s - (1 - a_t).sqrt() * v
+    eps = a_t.sqrt() * v + (1 - a_t).sqrt() * s
+    assert torch.allclose(out, a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps)
