@@ -1146,7 +1146,7 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
     a.W = w; a.bias = bias; a.N = n; a.xin = x; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps; a.hout = xnorm_out;
     a.out = y; a.resid = resid;
     hipError_t e;
-    if (B > 4) {   // batched kernels: LayerNorm rows first (same arithmetic as the fused prologue), then one pass per 16 rows
+    if (B > 4) {   // batched kernels: LayerNorm rows first (same arithmetic as the fused prologue), then passes of 32 (VALU: 16) rows
         float* tmp = nullptr;
         if (ln_w) {
             if (k != 1536) return fail(ER_ERR_UNSUPPORTED, "er_k_gemv: LayerNorm prologue needs k=1536");

@@ -204,7 +204,10 @@ int er_profile_decode_kernels(er_ctx* ctx, int repeats, float* avg_us_out, doubl
 int er_last_decode_ms(er_ctx* ctx, float* ms_out);
 
 /* ---- single-kernel entry points (unit tests call these through the ABI) ---- */
-/* y[b,n] = act(sum_k W[n,k] x[b,k] + bias[n]) (+resid) ; ln_w != NULL -> x = LayerNorm(x) first */
+/* y[b,n] = act(sum_k W[n,k] x[b,k] + bias[n]) (+resid) ; ln_w != NULL -> x = LayerNorm(x) first.
+ * batch <= 4: the single-row decode kernels; batch > 4: the batched ones exactly as the decode step picks them
+ * (matrix-core kernels on a tiled copy of W for the fc1- and fc2-shaped cases, VALU kernels for the narrow ones;
+ * env ER_BATCHED_VALU=1 forces the VALU kernels) */
 int er_k_gemv(const float* w_dev, const float* bias_dev, const float* x_dev, const float* ln_w_dev,
               const float* ln_b_dev, const float* resid_dev, float* y_dev, float* xnorm_out_dev,
               int batch, int n, int k, int relu, float eps, void* stream);
