@@ -193,7 +193,7 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     const bool fast = cfg->weight_dtype == ER_F16 && cfg->kv_dtype == ER_F16;
     if (!exact && !fast)
         return fail(ER_ERR_UNSUPPORTED, "built modes: fp32 weights + fp32 KV (exact) or fp16 weights + fp16 KV (fast)");
-    if (cfg->vocab_size > 1024) return fail(ER_ERR_UNSUPPORTED, "vocab_size > 1024");
+    if (cfg->vocab_size > ER_HEAD_MAX_VOCAB) return fail(ER_ERR_UNSUPPORTED, "vocab_size > %d", ER_HEAD_MAX_VOCAB);
     if (cfg->cond_mode == ER_COND_POINT && (cfg->point_hidden_dim != 1024 || cfg->point_hidden_dim % cfg->point_num_heads))
         return fail(ER_ERR_UNSUPPORTED, "point encoder width %d not built (1024)", cfg->point_hidden_dim);
     HIPCHK(hipSetDevice(device));
@@ -1307,24 +1307,28 @@ extern "C" int er_k_sample_head(const float* logits, const er_decode_params* p, 
 }
 
 // ------------------------------------------------------------------------------------ detokenise (host)
-extern "C" int er_meto_decode(const int32_t* tokens, int n, int bins, float* v, int32_t* f, int32_t* t, int32_t* nv,
+extern "C" int er_meto_decode(const int32_t* tokens, int n, int bins, int backend, float* v, int32_t* f, int32_t* t, int32_t* nv,
                               int32_t* nf, int32_t* nt) {
     if (n < 0 || bins <= 0 || (n > 0 && !tokens) || !v || !f || !t || !nv || !nf || !nt)
         return fail(ER_ERR_INVALID, "er_meto_decode: bad argument");
-    const MetoCounts c = meto_decode_lr_absco(tokens, n, bins, v, f, t);
+    if (backend != ER_METO_LR_ABSCO && backend != ER_METO_LR) return fail(ER_ERR_UNSUPPORTED, "meto backend %d (LR_ABSCO = 0, LR = 1)", backend);
+    const MetoCounts c = backend == ER_METO_LR ? meto_decode_lr(tokens, n, bins, v, f, t) : meto_decode_lr_absco(tokens, n, bins, v, f, t);
     *nv = c.vertices; *nf = c.faces; *nt = c.face_types;
     return ER_OK;
 }
 
-extern "C" int er_meto_encode(const float* vertices, int nv, const int32_t* faces, int nf, int bins, int32_t* tokens,
+extern "C" int er_meto_encode(const float* vertices, int nv, const int32_t* faces, int nf, int bins, int backend, int32_t* tokens,
                               int32_t* n_tokens, int32_t* face_order, int32_t* face_type, int32_t* n_faces_out) {
+    if (backend != ER_METO_LR_ABSCO && backend != ER_METO_LR) return fail(ER_ERR_UNSUPPORTED, "meto backend %d (LR_ABSCO = 0, LR = 1)", backend);
     if (nv < 0 || nf < 0 || bins <= 0 || !tokens || !n_tokens || !face_order || !face_type || !n_faces_out ||
         (nv > 0 && !vertices) || (nf > 0 && !faces))
         return fail(ER_ERR_INVALID, "er_meto_encode: bad argument");
     for (int i = 0; i < 3 * nf; ++i)
         if (faces[i] < 0 || faces[i] >= nv) return fail(ER_ERR_INVALID, "er_meto_encode: face index %d out of range", faces[i]);
-    const MetoEncodeOut o = meto_encode_lr_absco(vertices, nv, faces, nf, bins);
-    if ((long long)o.tokens.size() > 10LL * nf) return fail(ER_ERR_CAPACITY, "er_meto_encode: token bound exceeded");
+    const MetoEncodeOut o = backend == ER_METO_LR ? meto_encode<true>(vertices, nv, faces, nf, bins) : meto_encode<false>(vertices, nv, faces, nf, bins);
+    const long long per = backend == ER_METO_LR ? 2 : 1;      // LR may open a sub-mesh on an already covered face (see meto_encode.h)
+    if ((long long)o.tokens.size() > 10LL * per * nf || (long long)o.face_order.size() > per * nf)
+        return fail(ER_ERR_CAPACITY, "er_meto_encode: token bound exceeded");
     memcpy(tokens, o.tokens.data(), o.tokens.size() * sizeof(int32_t));
     memcpy(face_order, o.face_order.data(), o.face_order.size() * sizeof(int32_t));
     memcpy(face_type, o.face_type.data(), o.face_type.size() * sizeof(int32_t));

@@ -75,6 +75,10 @@ __device__ __forceinline__ int grammar_update(int grammar, int t, int counter, i
     return counter;
 }
 
+// Largest vocabulary the sampling head handles: the reference's are 515 (no meto), 518 (LR_ABSCO) and 1030 (LR, 2*512 + 6;
+// core/models.py:78-84).
+constexpr int ER_HEAD_MAX_VOCAB = 1088;
+
 // grid (B), 256 threads.  Dynamic LDS: vocab floats + 2*vocab ints-ish scratch (see launch).
 __global__ __launch_bounds__(ER_WG) void sample_head_kernel(const float* logits, const DecodeParamsDev* pp, GenState st,
                                                             long long* out_ids, int out_ld) {
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(ER_WG) void sample_head_kernel(const float* logits,
     if (P.mode == 1) {   // sample: TopK(top_k) -> softmax -> categorical
         // k-th largest value counting duplicates: remove one maximum k-1 times (wave 0, scores in registers)
         if (wid == 0) {
-            constexpr int MAXPL = 16;              // supports vocab <= 1024
+            constexpr int MAXPL = ER_HEAD_MAX_VOCAB / 64;   // scores of the whole vocabulary in wave 0's registers
             float v[MAXPL];
 #pragma unroll
             for (int j = 0; j < MAXPL; ++j) { const int i = j * 64 + lane; v[j] = (i < V) ? sc[i] : -INFINITY; }

@@ -56,4 +56,53 @@ inline MetoCounts meto_decode_lr_absco(const int32_t* tok, int n, int bins, floa
     return {nv, nf, nt};
 }
 
+// The LR backend (Options.meto_backend = 'LR'): same stream shape, RELATIVE coordinates with parallelogram
+// prediction; Engine_LR::decode (meto/include/meto/engine_lr.h:171-253).  A coordinate token t stands for
+// t - bins - 3 (restore_coord, :53-56; negative tokens pass through unchanged).  BOM: v0 absolute, v1 = v0 + d,
+// v2 = v1 + d; L: v = v0 + v2 - v1 + d; R: v = v0 + v1 - v2 + d; window updates as in LR_ABSCO.
+inline MetoCounts meto_decode_lr(const int32_t* tok, int n, int bins, float* vout, int32_t* fout, int32_t* tout) {
+    enum { OP_L = 0, OP_R = 1, OP_BOM = 2, OP_NUM = 3 };
+    struct P { int x, y, z, i; };
+    int nv = 0, nf = 0, nt = 0;
+    P v0{0, 0, 0, -1}, v1{0, 0, 0, -1}, v2{0, 0, 0, -1};
+    auto restore = [&](int t) { return t < 0 ? t : t - bins - OP_NUM; };
+    auto emit = [&](P& p) {
+        const int q[3] = {p.x, p.y, p.z};
+        for (int k = 0; k < 3; ++k) vout[3 * nv + k] = (float)(((double)(float)q[k] + 0.5) / bins * 2 - 1);
+        p.i = nv++;
+    };
+    for (int i = 0; i < n; ++i) {
+        if (tok[i] == OP_BOM) {
+            if (i + 9 >= n) break;
+            v0 = {restore(tok[i + 1]), restore(tok[i + 2]), restore(tok[i + 3]), -1};
+            v1 = {v0.x + restore(tok[i + 4]), v0.y + restore(tok[i + 5]), v0.z + restore(tok[i + 6]), -1};
+            v2 = {v1.x + restore(tok[i + 7]), v1.y + restore(tok[i + 8]), v1.z + restore(tok[i + 9]), -1};
+            emit(v0); emit(v1); emit(v2);
+            fout[3 * nf] = v0.i; fout[3 * nf + 1] = v1.i; fout[3 * nf + 2] = v2.i; ++nf;
+            if (i != 0) tout[nt++] = OP_BOM;
+            i += 9;
+        } else {
+            if (tok[i] >= OP_NUM) break;
+            if (i + 3 >= n) break;
+            const int op = tok[i];
+            const int dx = restore(tok[i + 1]), dy = restore(tok[i + 2]), dz = restore(tok[i + 3]);
+            if (op == OP_L) {
+                P v{v0.x + v2.x - v1.x + dx, v0.y + v2.y - v1.y + dy, v0.z + v2.z - v1.z + dz, -1};
+                emit(v);
+                fout[3 * nf] = v.i; fout[3 * nf + 1] = v0.i; fout[3 * nf + 2] = v2.i; ++nf;
+                v1 = v0; v0 = v;
+            } else if (op == OP_R) {
+                P v{v0.x + v1.x - v2.x + dx, v0.y + v1.y - v2.y + dy, v0.z + v1.z - v2.z + dz, -1};
+                emit(v);
+                fout[3 * nf] = v.i; fout[3 * nf + 1] = v1.i; fout[3 * nf + 2] = v0.i; ++nf;
+                v2 = v0; v0 = v;
+            }
+            tout[nt++] = op;
+            i += 3;
+        }
+    }
+    tout[nt++] = OP_BOM;
+    return {nv, nf, nt};
+}
+
 }  // namespace er

@@ -1,4 +1,4 @@
-// Native LR_ABSCO mesh tokeniser (encode side; host C++, CPU pointer-chasing, not on the decode hot
+// Native LR_ABSCO / LR mesh tokeniser (encode side; host C++, CPU pointer-chasing, not on the decode hot
 // path - scope row f4).  Index-based restatement of the reference's half-edge build + traversal:
 //   Mesh::Mesh            meto/include/meto/mesh.h:153-262   (discretise, twin edges, boundary marks,
 //                                                            half-edge / face ordering, components)
@@ -117,17 +117,30 @@ struct MetoMesh {
 
 struct MetoEncodeOut { std::vector<int32_t> tokens, face_order, face_type; };
 
-inline MetoEncodeOut meto_encode_lr_absco(const float* vtx, int nv, const int32_t* tri, int nf, int bins) {
+// RELATIVE = false: LR_ABSCO (absolute coordinates, shorter-boundary-loop heuristic at a split, visited check on deferred
+// sub-meshes).  RELATIVE = true: Engine_LR (meto/include/meto/engine_lr.h:59-168): coordinates relative to the previous
+// vertex / to the parallelogram prediction v(c) + v(twin) - v(next) - v(prev), offset by bins + 3 (out-of-range -> -1,
+// :47-51); a split always walks right first and re-opens the left side as a new sub-mesh WITHOUT checking whether the
+// strip just walked has already covered it (:121-127, :130 - so a face can be emitted twice, as in the reference).
+template <bool RELATIVE>
+inline MetoEncodeOut meto_encode(const float* vtx, int nv, const int32_t* tri, int nf, int bins) {
     enum { OP_L = 0, OP_R = 1, OP_BOM = 2, OP_NUM = 3 };
     MetoMesh M(vtx, nv, tri, nf, bins);
     auto& H = M.hes;
     auto& V = M.verts;
     auto& F = M.faces;
     MetoEncodeOut out;
+    auto rel = [&](int d) { return (d < -bins || d >= bins) ? -1 : d + bins + OP_NUM; };
     auto coord = [&](int v) {
         out.tokens.push_back(V[v].x + OP_NUM);
         out.tokens.push_back(V[v].y + OP_NUM);
         out.tokens.push_back(V[v].z + OP_NUM);
+    };
+    auto coord_delta = [&](int v, int from) {            // v - from (from < 0: absolute)
+        const int fx = from < 0 ? 0 : V[from].x, fy = from < 0 ? 0 : V[from].y, fz = from < 0 ? 0 : V[from].z;
+        out.tokens.push_back(rel(V[v].x - fx));
+        out.tokens.push_back(rel(V[v].y - fy));
+        out.tokens.push_back(rel(V[v].z - fz));
     };
     auto face_visited = [&](int h) { return h < 0 || F[H[h].t].m != 0; };   // "o == NULL || o->t->m"
     std::vector<int> pending;                         // sub-meshes whose traversal was deferred at a split (LIFO = recursion order)
@@ -137,9 +150,10 @@ inline MetoEncodeOut meto_encode_lr_absco(const float* vtx, int nv, const int32_
         while (!pending.empty()) {
             int c = pending.back();
             pending.pop_back();
-            if (F[H[c].t].m) continue;                // compress_submesh: already visited (hole / handle)
+            if (!RELATIVE && F[H[c].t].m) continue;   // compress_submesh: already visited (hole / handle); LR has no such check
             out.tokens.push_back(OP_BOM);
-            coord(H[c].v); coord(H[c].s); coord(H[c].e);
+            if (RELATIVE) { coord_delta(H[c].v, -1); coord_delta(H[c].s, H[c].v); coord_delta(H[c].e, H[c].s); }
+            else { coord(H[c].v); coord(H[c].s); coord(H[c].e); }
             V[H[c].s].m = 1; V[H[c].e].m = 1;
             bool init = true;
             for (;;) {                                // compress_face chain
@@ -154,7 +168,14 @@ inline MetoEncodeOut meto_encode_lr_absco(const float* vtx, int nv, const int32_
                             std::swap(e.n, e.p);
                         }
                     }
-                    coord(H[c].v);
+                    if (RELATIVE) {               // parallelogram correction (twin read after a possible flip, like the reference)
+                        const int vo = H[H[c].o].v, vn = H[H[c].n].v, vp = H[H[c].p].v;
+                        out.tokens.push_back(rel(V[H[c].v].x + V[vo].x - V[vn].x - V[vp].x));
+                        out.tokens.push_back(rel(V[H[c].v].y + V[vo].y - V[vn].y - V[vp].y));
+                        out.tokens.push_back(rel(V[H[c].v].z + V[vo].z - V[vn].z - V[vp].z));
+                    } else {
+                        coord(H[c].v);
+                    }
                 }
                 init = false;
                 const bool tip = V[H[c].v].m != 0;
@@ -173,6 +194,10 @@ inline MetoEncodeOut meto_encode_lr_absco(const float* vtx, int nv, const int32_
                 } else if (right_v) {
                     out.tokens.push_back(OP_R); out.face_type.push_back(OP_R);
                     c = left;
+                } else if (RELATIVE) {                // "S" in Engine_LR: right strip first, left side re-opened afterwards
+                    out.tokens.push_back(OP_L); out.face_type.push_back(OP_L);
+                    pending.push_back(left);
+                    c = right;
                 } else {                              // "S": split - walk both unvisited boundary loops, shorter side first
                     int len_left = 0, len_right = 0;
                     for (int cur = right;;) {

@@ -1,8 +1,8 @@
 """``meto`` mesh tokenizer surface for the decode path (reference: meto/meto/__init__.py:21-54).
 
-The ``LR_ABSCO`` backend (ArAE preset) is native C++ behind ``er_meto_decode`` (the step right after
-the decode loop, row f1) and ``er_meto_encode`` (training data / partial-mesh completion, row f4),
-both bit-exact against the reference's own engine.
+The ``LR_ABSCO`` (ArAE preset) and ``LR`` backends - the two ``Options.meto_backend`` admits - are native C++ behind
+``er_meto_decode`` (the step right after the decode loop, row f1) and ``er_meto_encode`` (training data /
+partial-mesh completion, row f4), both bit-exact against the reference's own engines.
 Also the reference's ``detokenize_mesh`` / ``save_mesh`` (core/provider.py:39-66,112-147)
 without trimesh: meshes are ``(vertices float64 [V,3], faces int64 [F,3])`` tuples.
 """
@@ -18,11 +18,13 @@ from . import native
 
 class Engine:
     def __init__(self, discrete_bins: int, verbose: bool = False, backend: str = "LR_ABSCO"):
-        if backend != "LR_ABSCO":
-            raise NotImplementedError(f"meto backend {backend!r}: only LR_ABSCO (the ArAE preset) is built")
+        if backend not in ("LR_ABSCO", "LR"):
+            raise NotImplementedError(f"meto backend {backend!r}: LR_ABSCO and LR (the values of Options.meto_backend) are built")
+        self.backend = backend
+        self._backend_id = native.ER_METO_LR if backend == "LR" else native.ER_METO_LR_ABSCO
         self.discrete_bins = discrete_bins
         self.verbose = verbose
-        self.num_base_tokens = discrete_bins
+        self.num_base_tokens = discrete_bins * 2 if backend == "LR" else discrete_bins      # meto/meto/__init__.py:30-37
         self.num_special_tokens = 3
         self.num_tokens = self.num_base_tokens + self.num_special_tokens
         self._lib = native.load_library()
@@ -32,12 +34,13 @@ class Engine:
         v = np.ascontiguousarray(np.asarray(vertices, dtype=np.float32).reshape(-1, 3))
         f = np.ascontiguousarray(np.asarray(faces, dtype=np.int32).reshape(-1, 3))
         nf = len(f)
-        tok = np.empty((max(1, 10 * nf),), np.int32)
-        order = np.empty((max(1, nf),), np.int32)
-        ftype = np.empty((max(1, nf),), np.int32)
+        per = 2 if self.backend == "LR" else 1
+        tok = np.empty((max(1, 10 * per * nf),), np.int32)
+        order = np.empty((max(1, per * nf),), np.int32)
+        ftype = np.empty((max(1, per * nf),), np.int32)
         nt, no = C.c_int32(), C.c_int32()
         i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
-        native.check(self._lib.er_meto_encode(v.ctypes.data_as(f32p), len(v), f.ctypes.data_as(i32p), nf, self.discrete_bins,
+        native.check(self._lib.er_meto_encode(v.ctypes.data_as(f32p), len(v), f.ctypes.data_as(i32p), nf, self.discrete_bins, self._backend_id,
                                               tok.ctypes.data_as(i32p), C.byref(nt), order.ctypes.data_as(i32p),
                                               ftype.ctypes.data_as(i32p), C.byref(no)), "er_meto_encode")
         return (tok[: nt.value].astype(np.int64), order[: no.value].astype(np.int64), ftype[: no.value].astype(np.int64))
@@ -51,7 +54,7 @@ class Engine:
         t = np.empty((n // 4 + 3,), np.int32)
         nv, nf, nt = C.c_int32(), C.c_int32(), C.c_int32()
         i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
-        native.check(self._lib.er_meto_decode(tok.ctypes.data_as(i32p), n, self.discrete_bins, v.ctypes.data_as(f32p),
+        native.check(self._lib.er_meto_decode(tok.ctypes.data_as(i32p), n, self.discrete_bins, self._backend_id, v.ctypes.data_as(f32p),
                                               f.ctypes.data_as(i32p), t.ctypes.data_as(i32p), C.byref(nv), C.byref(nf),
                                               C.byref(nt)), "er_meto_decode")
         return (v[: nv.value].astype(np.float64), f[: nf.value].astype(np.int64), t[: nt.value].astype(np.int64))

@@ -18,6 +18,7 @@ ER_F32, ER_F16, ER_BF16 = 0, 1, 2
 ER_COND_NONE, ER_COND_POINT, ER_COND_POINT_LATENT = 0, 1, 2
 ER_GREEDY, ER_SAMPLE = 0, 1
 ER_GRAMMAR_NONE, ER_GRAMMAR_NAIVE9, ER_GRAMMAR_LR_ABSCO = 0, 1, 2
+ER_METO_LR_ABSCO, ER_METO_LR = 0, 1
 ER_NUM_KERNEL_KINDS = 8
 
 # every symbol include/edgerunner_hip.h declares (tests/test_abi.py checks the .so exports them all)
@@ -86,8 +87,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.er_profile_decode_kernels.argtypes = [vp, ci, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]
     lib.er_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
     i32p = C.POINTER(C.c_int32)
-    lib.er_meto_decode.argtypes = [i32p, ci, ci, C.POINTER(C.c_float), i32p, i32p, i32p, i32p, i32p]
-    lib.er_meto_encode.argtypes = [C.POINTER(C.c_float), ci, i32p, ci, ci, i32p, i32p, i32p, i32p, i32p]
+    lib.er_meto_decode.argtypes = [i32p, ci, ci, ci, C.POINTER(C.c_float), i32p, i32p, i32p, i32p, i32p]
+    lib.er_meto_encode.argtypes = [C.POINTER(C.c_float), ci, i32p, ci, ci, ci, i32p, i32p, i32p, i32p, i32p]
     lib.er_dit_create.argtypes = [C.POINTER(ErDitConfig), ci, C.POINTER(vp)]
     lib.er_dit_destroy.argtypes = [vp]
     lib.er_dit_load_tensor.argtypes = [vp, C.c_char_p, vp, ci, ci, C.POINTER(C.c_int64), ci]

@@ -137,20 +137,26 @@ int er_feed(er_ctx* ctx, const int32_t* ids_host, void* stream);
 int er_decode(er_ctx* ctx, const er_decode_params* p, int64_t* out_ids_dev,
               int32_t* n_steps_host, void* stream);
 
-/* ---- detokenise (the step right after the decode loop; host code, no device work) ----
- * Engine_LR_ABSCO::decode (meto/include/meto/engine_lr_absco.h:223-295) + Vertex::undiscrete
- * (meto/include/meto/mesh.h:36-42), reached from save_mesh/detokenize_mesh
- * (core/provider.py:39-66,112-147).  tokens_host = meto ids (model ids - 3, cut at EOS).
+/* ---- mesh tokenizer (host code, no device work): the reference's pybind11 module meto (meto/src/bindings.cpp,
+ * meto.Engine(discrete_bins, verbose, backend), meto/meto/__init__.py:21-54) for the backends Options.meto_backend
+ * admits (core/options.py:26). */
+enum er_meto_backend { ER_METO_LR_ABSCO = 0, ER_METO_LR = 1 };
+
+/* detokenise - the step right after the decode loop.
+ * Engine_LR_ABSCO::decode (meto/include/meto/engine_lr_absco.h:223-295) / Engine_LR::decode
+ * (meto/include/meto/engine_lr.h:171-253) + Vertex::undiscrete (meto/include/meto/mesh.h:36-42), reached from
+ * save_mesh/detokenize_mesh (core/provider.py:39-66,112-147).  tokens_host = meto ids (model ids - 3, cut at EOS).
  * Capacities: vertices_out float[3*(n/3+3)], faces_out int32[3*(n/4+2)], face_type_out int32[n/4+3]. */
-int er_meto_decode(const int32_t* tokens_host, int n_tokens, int discrete_bins, float* vertices_out,
+int er_meto_decode(const int32_t* tokens_host, int n_tokens, int discrete_bins, int backend, float* vertices_out,
                    int32_t* faces_out, int32_t* face_type_out, int32_t* n_vertices, int32_t* n_faces,
                    int32_t* n_face_types);
 
-/* Engine_LR_ABSCO::encode (meto/include/meto/engine_lr_absco.h:66-220) over Mesh::Mesh
- * (meto/include/meto/mesh.h:153-262): vertices float[3*n_vertices] in [-1,1], faces int32[3*n_faces].
- * tokens_out capacity must be >= 10*n_faces; face_order_out / face_type_out capacity >= n_faces. */
+/* Engine_LR_ABSCO::encode (meto/include/meto/engine_lr_absco.h:66-220) / Engine_LR::encode
+ * (meto/include/meto/engine_lr.h:59-168) over Mesh::Mesh (meto/include/meto/mesh.h:153-262):
+ * vertices float[3*n_vertices] in [-1,1], faces int32[3*n_faces].  Capacities: tokens_out >= 10*n_faces and
+ * face_order_out / face_type_out >= n_faces for LR_ABSCO; twice that for LR (it can emit a face twice). */
 int er_meto_encode(const float* vertices_host, int n_vertices, const int32_t* faces_host, int n_faces,
-                   int discrete_bins, int32_t* tokens_out, int32_t* n_tokens, int32_t* face_order_out,
+                   int discrete_bins, int backend, int32_t* tokens_out, int32_t* n_tokens, int32_t* face_order_out,
                    int32_t* face_type_out, int32_t* n_faces_out);
 
 /* ---- DiT image-conditioned front-end (scope row f3): core/transformer/dit.py + core/models_dit.py::MDiT ----

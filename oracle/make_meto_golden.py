@@ -1,5 +1,5 @@
-"""TEST INFRASTRUCTURE ONLY (build container).  Produces tests/golden/meto_lr_absco.npz with the
-reference's own meto engine (compiled by oracle/build_ref.sh into oracle/_ref/): token streams of
+"""TEST INFRASTRUCTURE ONLY (build container).  Produces tests/golden/meto_lr_absco.npz and meto_lr.npz with the
+reference's own meto engines (compiled by oracle/build_ref.sh into oracle/_ref/): token streams of
 procedurally generated meshes (encode) and the decode of those and of random / malformed streams."""
 import os
 import subprocess
@@ -46,20 +46,22 @@ def torus(nu, nv):
     return np.array(v), np.array(f)
 
 
-def random_stream(rng, n_ops, bins):
+def random_stream(rng, n_ops, n_coord):
     t = []
     for k in range(n_ops):
         if k == 0 or rng.random() < 0.15:
-            t += [2] + list(rng.integers(3, 3 + bins, 9))
+            t += [2] + list(rng.integers(3, 3 + n_coord, 9))
         else:
-            t += [int(rng.integers(0, 2))] + list(rng.integers(3, 3 + bins, 3))
+            t += [int(rng.integers(0, 2))] + list(rng.integers(3, 3 + n_coord, 3))
     return np.array(t, np.int64)
 
 
-def main():
+def main(backend="LR_ABSCO"):
     out = {}
     bins = 512
-    eng = _meto.Engine_LR_ABSCO(bins, False)
+    make = {"LR_ABSCO": _meto.Engine_LR_ABSCO, "LR": _meto.Engine_LR}[backend]
+    n_coord = bins if backend == "LR_ABSCO" else 2 * bins          # coordinate alphabet (meto/meto/__init__.py:30-37)
+    eng = make(bins, False)
     meshes = {"cube": cube(), "grid7": grid(7), "torus": torus(12, 8),
               "two_parts": (np.concatenate([cube()[0] * 0.5 - 0.4, cube()[0] * 0.5 + 0.4]),
                             np.concatenate([cube()[1], cube()[1] + 8]))}
@@ -69,7 +71,7 @@ def main():
         streams[name] = np.asarray(tokens, np.int64)
     rng = np.random.default_rng(0)
     for k in range(6):
-        streams[f"rand{k}"] = random_stream(rng, int(rng.integers(1, 400)), bins)
+        streams[f"rand{k}"] = random_stream(rng, int(rng.integers(1, 400)), n_coord)
     base = streams["grid7"]
     streams["trunc_mid_vertex"] = base[:-2]
     streams["trunc_in_bom"] = base[:5]
@@ -78,14 +80,15 @@ def main():
     streams["empty"] = np.zeros((0,), np.int64)
     streams["starts_with_op"] = np.concatenate([[0, 10, 11, 12], base])[4:]  # well-formed after trimming
     for name, t in streams.items():
-        v, f, ft = _meto.Engine_LR_ABSCO(bins, False).decode(t.tolist())
+        v, f, ft = make(bins, False).decode(t.tolist())
         out[f"{name}.tokens"] = t
         out[f"{name}.vertices"] = np.asarray(v, np.float64).reshape(-1, 3)
         out[f"{name}.faces"] = np.asarray(f, np.int64).reshape(-1, 3)
         out[f"{name}.face_type"] = np.asarray(ft, np.int64)
         print(name, len(t), out[f"{name}.vertices"].shape, out[f"{name}.faces"].shape)
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "meto_lr_absco.npz"), **out)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"meto_{backend.lower()}.npz"), **out)
 
 
 if __name__ == "__main__":
-    main()
+    for b in (sys.argv[1:] or ["LR_ABSCO", "LR"]):
+        main(b)

@@ -304,6 +304,27 @@ def test_sample_head_greedy_matches_oracle_processors(grammar):
             assert uo[0] == (0 if ref == 2 else 1)
 
 
+def test_sample_head_wide_vocabulary_topk():
+    """V = 1030 (the LR tokenizer backend): ids above 1024 must be reachable by argmax and by the top-k sampler."""
+    import arae_oracle as O
+    from edgerunner_amd import kernels as K
+    V = 1030
+    logits = rnd(1, V, seed=53)
+    logits[0, 1029] = 9.0
+    nt, _, _ = K.sample_head(logits, 0, 0, 3, [7], [0], [1])
+    assert nt[0] == 1029
+    logits[0, 1027] = 9.0
+    logits[0, 1025] = 8.5
+    seen = set()
+    for step in range(150):
+        nt, _, _ = K.sample_head(logits, 1, 0, step, [7], [0], [1], top_k=3, seed=99)
+        u = K.philox_uniform(99, step, 0)
+        ref = O.sample_from_uniform(O.top_k_filter(logits.cpu(), 3)[0], u)
+        assert nt[0] in (1025, 1027, 1029) and (nt[0] == ref or abs(nt[0] - ref) <= 4)
+        seen.add(nt[0])
+    assert seen == {1025, 1027, 1029}
+
+
 def test_sample_head_finished_rows_emit_pad():
     from edgerunner_amd import kernels as K
     logits = rnd(3, 518, seed=51)

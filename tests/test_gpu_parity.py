@@ -296,6 +296,33 @@ def test_fast_mode_batched_rows_bit_identical():
         assert_ids(toks[r], one[0], f"fp16 row {r} of a 6-row batch vs its single run")
 
 
+# ------------------------------------------------------------------ Options.meto_backend = 'LR' (vocabulary 2*512 + 6 = 1030)
+def test_lr_backend_vocab_1030_greedy_and_detokenise():
+    """The other tokenizer backend the reference's Options admit (core/options.py:26, core/models.py:78-84): a
+    1030-word vocabulary, same grammar; greedy ids must equal the CPU oracle's (live, 2 layers), the sampling head
+    must stay inside the top-k set at that width, and the stream must detokenise with the LR engine."""
+    import arae_oracle as O
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.meto import Engine
+    lmm = make_lmm(meto_backend="LR")
+    assert lmm.vocab_size == 1030
+    sd = W.make_state_dict(lmm.opt, 0, "perturbed")
+    pc = W.synthetic_point_cloud(2, 512)
+    want = O.lmm_generate_ids(sd, lmm.opt, pc, 1000, max_new_tokens=40, min_new_tokens=40).numpy()[0]
+    _, toks = lmm.generate(pc.to(DEV), 1000, tokenizer=object(), max_new_tokens=40, min_new_tokens=40)
+    assert_ids(toks[0], want, "LR-backend greedy ids vs CPU oracle")
+    assert toks[0].max() > 518, "the run should use the upper half of the LR alphabet"
+    v, f, _ = Engine(512, backend="LR").decode(toks[0] - 3)
+    assert f.shape[0] >= 1 and v.shape[0] >= f.shape[0] + 2 and np.isfinite(v).all()
+    lmm.opt.generate_mode = "sample"
+    try:
+        a = lmm.generate_ids(pc.to(DEV), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64, seed=3)
+        b = lmm.generate_ids(pc.to(DEV), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64, seed=3)
+    finally:
+        lmm.opt.generate_mode = "greedy"
+    assert torch.equal(a, b) and int(a.max()) < 1030 and int(a.min()) >= 3
+
+
 # ------------------------------------------------------------------ error behaviour of the boundary
 def test_boundary_errors_are_loud():
     from edgerunner_amd import native
