@@ -90,3 +90,49 @@ def test_synthetic_inputs_are_deterministic():
     k2, t2 = next(iter(W.iter_state_dict(opt, 0, "perturbed")))
     assert k == k2 and torch.equal(t, t2)
     assert torch.equal(W.point_basis(24)[1, 8:16], torch.pow(2, torch.arange(8)).float() * np.pi)
+
+
+# ------------------------------------------------------------------ mesh / point-cloud I/O used by infer.py
+def test_meshio_formats_and_surface_sampling(tmp_path):
+    import struct
+    from edgerunner_amd import meshio
+    v = np.array([[x, y, z] for x in (0.0, 2.0) for y in (0.0, 1.0) for z in (0.0, 1.0)])
+    quads = [[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1], [2, 3, 7, 6], [0, 2, 6, 4], [1, 5, 7, 3]]
+    # OBJ: 1-based, v/vt/vn triplets, negative (relative) indices, polygons are fan-triangulated
+    with open(tmp_path / "box.obj", "w") as fh:
+        for p in v:
+            fh.write(f"v {p[0]} {p[1]} {p[2]}\n")
+        for q in quads[:5]:
+            fh.write("f " + " ".join(f"{i + 1}/1/1" for i in q) + "\n")
+        fh.write("f " + " ".join(str(i - 8) for i in quads[5]) + "\n")
+    ov, of = meshio.load_mesh(str(tmp_path / "box.obj"))
+    assert ov.shape == (8, 3) and of.shape == (12, 3) and of.min() == 0 and of.max() == 7
+    assert of[-2].tolist() == [1, 5, 7] and of[-1].tolist() == [1, 7, 3]
+    # ASCII PLY round trip, binary little-endian PLY with an extra vertex property
+    meshio.save_ply(str(tmp_path / "a.ply"), ov, of)
+    av, af = meshio.load_mesh(str(tmp_path / "a.ply"))
+    assert np.allclose(av, ov) and np.array_equal(af, of)
+    with open(tmp_path / "b.ply", "wb") as fh:
+        fh.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 8\nproperty float x\nproperty float y\nproperty float z\n"
+                 b"property uchar red\nelement face 6\nproperty list uchar int vertex_indices\nend_header\n")
+        for p in v:
+            fh.write(struct.pack("<fffB", *p, 7))
+        for q in quads:
+            fh.write(struct.pack("<Biiii", 4, *q))
+    bv, bf = meshio.load_mesh(str(tmp_path / "b.ply"))
+    assert np.allclose(bv, v) and bf.shape == (12, 3)
+    with pytest.raises(ValueError):
+        meshio.load_mesh(str(tmp_path / "x.stl"))
+    # normalize_mesh (core/utils.py:69-75): longest side spans [-bound, bound], centred
+    n = meshio.normalize_mesh(ov, bound=0.95)
+    assert np.isclose(n[:, 0].max(), 0.95) and np.isclose(n[:, 0].min(), -0.95) and np.allclose(n.max(0) + n.min(0), 0)
+    # area-weighted surface sampling: deterministic per generator, on the surface, proportional to face area
+    pts = meshio.sample_surface(ov, of, 20000, np.random.default_rng(0))
+    assert np.array_equal(pts, meshio.sample_surface(ov, of, 20000, np.random.default_rng(0)))
+    on_face = (np.isclose(pts[:, 0], 0) | np.isclose(pts[:, 0], 2) | np.isclose(pts[:, 1], 0) | np.isclose(pts[:, 1], 1)
+               | np.isclose(pts[:, 2], 0) | np.isclose(pts[:, 2], 1))
+    assert on_face.all() and pts.min() >= 0 and pts[:, 0].max() <= 2
+    frac_small = (np.isclose(pts[:, 0], 0) | np.isclose(pts[:, 0], 2)).mean()      # the two 1x1 ends: 2 of 10 area units
+    assert abs(frac_small - 0.2) < 0.02
+    meshio.save_points_obj(str(tmp_path / "pc.obj"), pts[:5])
+    assert len(open(tmp_path / "pc.obj").read().splitlines()) == 5
