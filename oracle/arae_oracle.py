@@ -21,7 +21,12 @@ TopKLogitsWarper,MinNewTokensLengthLogitsProcessor}``; the installed 5.15
 cannot drive the reference's tuple KV cache (TypeError at modeling_opt.py:524).
 Its published algorithm is restated in :func:`generate` and anchored on the
 reference's call site (core/models.py:286-303) and patch (core/utils.py:118-141).
-The reference holds no golden vectors for this path.
+The reference holds no golden vectors for this path; the
+restated loop is instead checked id for id (greedy and, under a shared
+``torch.manual_seed``, sample mode; grammar closure, ``min_new_tokens``,
+pad-after-EOS, early stop) against the INSTALLED transformers'
+``GenerationMixin.generate`` driving a toy LM with the reference's
+``prepare_inputs_for_generation`` protocol: tests/test_hf_loop_pin.py.
 
 Every function cites the reference file:line it follows.
 """
