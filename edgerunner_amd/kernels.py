@@ -102,15 +102,22 @@ def sample_head(logits, mode, grammar, step, last_tok, counter, unfinished, top_
     return list(nt), list(co), list(uo)
 
 
-def philox_uniform(seed: int, step: int, row: int) -> float:
-    """Host replica of the device sampler's uniform draw (Philox4x32-10, key = seed,
-    counter = (step, row, 0, 0), u = (x0 >> 8) * 2^-24)."""
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., Random123) on the host: counter = 4 words, key = 2 words -> 4 words.
+    The same rounds and constants as ``philox4x32_10`` in csrc/k_head.h."""
     M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
-    c = [step & 0xFFFFFFFF, row & 0xFFFFFFFF, 0, 0]
-    k = [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF]
+    c = [int(x) & 0xFFFFFFFF for x in counter]
+    k = [int(x) & 0xFFFFFFFF for x in key]
     for _ in range(10):
         p0, p1 = M0 * c[0], M1 * c[2]
         c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF,
              p0 & 0xFFFFFFFF]
         k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
-    return float(c[0] >> 8) / 16777216.0
+    return c
+
+
+def philox_uniform(seed: int, step: int, row: int) -> float:
+    """Host replica of the device sampler's uniform draw (Philox4x32-10, key = seed,
+    counter = (step, row, 0, 0), u = (x0 >> 8) * 2^-24)."""
+    x = philox4x32_10((step, row, 0, 0), (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    return float(x[0] >> 8) / 16777216.0

@@ -136,3 +136,17 @@ def test_meshio_formats_and_surface_sampling(tmp_path):
     assert abs(frac_small - 0.2) < 0.02
     meshio.save_points_obj(str(tmp_path / "pc.obj"), pts[:5])
     assert len(open(tmp_path / "pc.obj").read().splitlines()) == 5
+
+
+def test_philox_host_replica_known_answers():
+    """The host replica of the device sampler's generator against the Random123 known-answer vectors for
+    philox4x32-10 (kat_vectors); the GPU tests then compare the device draw with this replica."""
+    from edgerunner_amd.kernels import philox4x32_10, philox_uniform
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for counter, key, want in kat:
+        assert tuple(philox4x32_10(counter, key)) == want
+    assert philox_uniform(0, 0, 0) == (0x6627e8d5 >> 8) / 2 ** 24
+    us = [philox_uniform(1234, t, b) for t in range(200) for b in range(4)]
+    assert 0.0 <= min(us) and max(us) < 1.0 and 0.4 < sum(us) / len(us) < 0.6 and len(set(us)) == len(us)
