@@ -110,6 +110,7 @@ struct er_ctx {
     float* skpart = nullptr;  // split-K partials of the batched fc2
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
+    int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
@@ -213,6 +214,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->rw_out = env_int("ER_RW_OUT", 1);
     c->attn_steps = env_int("ER_ATTN_STEPS", ATTN_STEPS_DEFAULT);
     if (c->attn_steps != 2 && c->attn_steps != 8) c->attn_steps = 4;
+    c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
+    c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -621,12 +624,13 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     return a;
 }
 
-static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int steps, bool kv_half, int B, hipStream_t st) {
-    return D == 96 ? launch_attn_partial_d<96>(a, steps, kv_half, B, st) : launch_attn_partial_d<64>(a, steps, kv_half, B, st);
+static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int steps, bool kv_half, int B, hipStream_t st, int ver = 2) {
+    return D == 96 ? launch_attn_partial_d<96>(a, steps, kv_half, B, st, ver) : launch_attn_partial_d<64>(a, steps, kv_half, B, st, ver);
 }
-static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int B, hipStream_t st) {
-    return D == 96 ? launch_attn_combine_d<96>(a, B, st) : launch_attn_combine_d<64>(a, B, st);
+static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int B, hipStream_t st, int ver = 2) {
+    return D == 96 ? launch_attn_combine_d<96>(a, B, st, ver) : launch_attn_combine_d<64>(a, B, st, ver);
 }
+static int env_version(const char* name) { const char* v = getenv(name); return (v && v[0] == '1') ? 1 : 2; }
 
 template <typename WT>
 static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, long long* out_ids, int out_ld) {
@@ -660,8 +664,8 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
             return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st);
         }
-        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st);
-        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st);
+        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st, c->attn_v);
+        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
@@ -1215,8 +1219,8 @@ extern "C" int er_k_attn_decode(const float* q, const void* k, const void* v, co
     a.q = q; a.kcache = k; a.vcache = v; a.len_dev = len_dev; a.part = part; a.out = out;
     a.H = heads; a.l_cap = l_cap; a.S = S; a.hidden = heads * head_dim; a.chunk = attn_chunk(steps, kv_half != 0);
     a.kv_bstride = (long long)heads * l_cap * head_dim; a.sqrt_d = sqrtf((float)head_dim);
-    hipError_t e = launch_attn_partial(a, head_dim, steps, kv_half != 0, B, st);
-    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st);
+    hipError_t e = launch_attn_partial(a, head_dim, steps, kv_half != 0, B, st, env_version("ER_ATTN_V"));
+    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st, env_version("ER_COMBINE_V"));
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(len_dev);
     hipFree(part);

@@ -35,6 +35,15 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return r;
 }
 
+// Same sum (identical order) through a caller-chosen 4-float slot and WITHOUT the trailing barrier: successive
+// reductions use different slots, so one barrier per reduction is enough.
+__device__ __forceinline__ float block_sum_slot(float v, float* slot) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (slot[0] + slot[1]) + (slot[2] + slot[3]);
+}
+
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;

@@ -223,14 +223,201 @@ __global__ __launch_bounds__(ER_WG) void attn_combine_kernel(AttnDecArgs a) {
     if (half == 0 && c < D) a.out[(long long)b * a.hidden + h * D + c] = (o + half1[c]) / l;
 }
 
+
+// ---- version 2 of both kernels (default; ER_ATTN_V=1 / ER_COMBINE_V=1 select the originals above for A/B runs).
+//
+// attn_decode2_kernel: same work decomposition and loads as attn_decode_kernel, but every WAVE runs its own softmax
+// (max / sum through shuffles only) and the four waves are merged once through LDS - one workgroup barrier on the
+// critical path instead of six (block_max + block_sum + the output combine).
+template <typename KT, int D, int STEPS>
+__global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
+    constexpr int NV = D / (EPL * LPK);
+    constexpr int KPW = 64 / LPK;
+    constexpr int KPS = ER_NWAVES * KPW;
+    constexpr int CHUNK = KPS * STEPS;
+    static_assert(D % (EPL * LPK) == 0, "head_dim must tile into 16-byte loads");
+    __shared__ __attribute__((aligned(16))) float ored[ER_NWAVES * D];
+    __shared__ float wm[ER_NWAVES], wl[ER_NWAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = lane & (LPK - 1), g = lane / LPK;
+    const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = attn_len(a, b);
+    const int k0 = s * CHUNK;
+    if (k0 >= len) return;
+    const int k1 = min(len, k0 + CHUNK);
+    const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
+    const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
+    const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
+
+    // this lane's query elements first: vector loads return in issue order, so anything issued behind the K/V
+    // stream would only become usable after ALL of it has landed
+    float qv[NV][EPL];
+    const float* qp = a.q + (long long)b * a.hidden + h * D;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+        }
+    f32x4 kreg[STEPS][NV], vreg[STEPS][NV];
+    bool valid[STEPS];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int kk = k0 + KPS * i + KPW * wid + g;
+        valid[i] = kk < k1;
+        const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) kreg[i][j] = __builtin_nontemporal_load(kr + j * LPK + p);
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int kk = k0 + KPS * i + KPW * wid + g;
+        const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) vreg[i][j] = __builtin_nontemporal_load(vr + j * LPK + p);
+    }
+    __builtin_amdgcn_sched_barrier(0);        // every K and V load is issued before the first score is computed
+
+    float sc[STEPS];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float kf[EPL];
+            kv_unpack<KT>(kreg[i][j], kf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
+        }
+#pragma unroll
+        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
+        mloc = fmaxf(mloc, sc[i]);
+    }
+    const float m = wave_max(mloc);           // -inf when the wave holds no valid key (ragged tail of the last chunk)
+
+    float pw[STEPS];
+    float lloc = 0.f;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        pw[i] = valid[i] ? expf(sc[i] - m) : 0.f;
+        if (p == 0) lloc += pw[i];
+    }
+    const float l = wave_sum(lloc);
+
+    float o[NV][EPL];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float vf[EPL];
+            kv_unpack<KT>(vreg[i][j], vf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
+        }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+#pragma unroll
+            for (int off = LPK; off < 64; off <<= 1) o[j][e] += __shfl_xor(o[j][e], off, 64);
+        }
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) ored[wid * D + (j * LPK + p) * EPL + e] = o[j][e];
+    }
+    if (lane == 0) { wm[wid] = m; wl[wid] = l; }
+    __syncthreads();
+    if (tid < D) {
+        const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));   // finite: the chunk holds at least one key
+        float ov = 0.f, lv = 0.f;
+#pragma unroll
+        for (int k = 0; k < ER_NWAVES; ++k) {
+            const float w = (wm[k] == -INFINITY) ? 0.f : expf(wm[k] - M);
+            ov = fmaf(ored[k * D + tid], w, ov);
+            lv = fmaf(wl[k], w, lv);
+        }
+        float* pout = a.part + (((long long)b * a.H + h) * a.S + s) * (D + 2);
+        pout[2 + tid] = ov;
+        if (tid == 0) { pout[0] = M; pout[1] = lv; }
+    }
+}
+
+// attn_combine2_kernel, grid (H, B), 256 threads: one memory round trip.  Thread (c, half) issues ALL of its column loads
+// (partials half, half+2, ... of a pass of up to 64 partials) before anything else; every wave then redundantly loads the
+// pass's {m_s, l_s} with lane = s, so the global max / weights / sum need wave shuffles only (no LDS, no barrier), and the
+// weight of partial s reaches the column accumulation through a wave-uniform readlane.  Longer contexts (> 64 partials,
+// L > 8192) run further passes with the usual running-max rescale.
+template <int D>
+__global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
+    const int CHUNK = a.chunk;
+    constexpr int W = D + 2, NP = 64, PER = NP / 2;
+    __shared__ float half1[128];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int n_act = (attn_len(a, b) + CHUNK - 1) / CHUNK;
+    const float* pb = a.part + ((long long)b * a.H + h) * a.S * W;
+    const int c = tid & 127, half = tid >> 7;          // half is wave-uniform (waves 0,1 -> 0; waves 2,3 -> 1)
+    const int cc = min(c, D - 1);
+    float M_run = -INFINITY, l_run = 0.f, o_run = 0.f;
+    for (int base = 0; base < n_act; base += NP) {
+        float v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int sidx = min(base + half + 2 * u, n_act - 1);   // clamped: loads stay unconditional
+            v[u] = pb[sidx * W + 2 + cc];
+        }
+        const int sl = base + lane;
+        const bool act = sl < n_act;
+        const float m_s = act ? pb[sl * W] : -INFINITY;
+        const float l_s = act ? pb[sl * W + 1] : 0.f;
+        const float M_new = fmaxf(M_run, wave_max(m_s));
+        const float w = act ? expf(m_s - M_new) : 0.f;
+        const float l_blk = wave_sum(l_s * w);
+        const float alpha = (M_run == -INFINITY) ? 0.f : expf(M_run - M_new);
+        float o = o_run * alpha;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const float wu = __shfl(w, half + 2 * u, 64);         // 0 for partials beyond n_act
+            o = fmaf(v[u], wu, o);
+        }
+        o_run = o;
+        l_run = l_run * alpha + l_blk;
+        M_run = M_new;
+    }
+    if (half == 1) half1[c] = o_run;
+    __syncthreads();
+    if (half == 0 && c < D) a.out[(long long)b * a.hidden + h * D + c] = (o_run + half1[c]) / l_run;
+}
+
 constexpr int ATTN_STEPS_DEFAULT = 4;          // fp32 KV: 128 keys per workgroup
 inline int attn_chunk(int steps, bool /*kv_half*/) { return 32 * steps; }   // fp16 KV: 64 keys/step x steps/2
 inline int attn_num_chunks(int l_cap, int chunk) { return (l_cap + chunk - 1) / chunk; }
 
 // `steps` is the fp32 step count (chunk = 32*steps keys); fp16 KV uses half as many steps for the same chunk.
 template <int D>
-inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv_half, int B, hipStream_t st) {
+inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv_half, int B, hipStream_t st, int version = 2) {
     const dim3 grid(a.S, a.H, B), blk(ER_WG);
+    if (version == 2) {
+        if (!kv_half) {
+            if (steps == 2) hipLaunchKernelGGL((attn_decode2_kernel<float, D, 2>), grid, blk, 0, st, a);
+            else if (steps == 8) hipLaunchKernelGGL((attn_decode2_kernel<float, D, 8>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((attn_decode2_kernel<float, D, 4>), grid, blk, 0, st, a);
+        } else {
+            if (steps == 2) hipLaunchKernelGGL((attn_decode2_kernel<_Float16, D, 1>), grid, blk, 0, st, a);
+            else if (steps == 8) hipLaunchKernelGGL((attn_decode2_kernel<_Float16, D, 4>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((attn_decode2_kernel<_Float16, D, 2>), grid, blk, 0, st, a);
+        }
+        return hipGetLastError();
+    }
     if (!kv_half) {
         if (steps == 2) hipLaunchKernelGGL((attn_decode_kernel<float, D, 2>), grid, blk, 0, st, a);
         else if (steps == 8) hipLaunchKernelGGL((attn_decode_kernel<float, D, 8>), grid, blk, 0, st, a);
@@ -243,8 +430,12 @@ inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv
     return hipGetLastError();
 }
 template <int D>
-inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int B, hipStream_t st) {
+inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int B, hipStream_t st, int version = 2) {
     const dim3 grid(a.H, B), blk(ER_WG);
+    if (version == 2) {
+        hipLaunchKernelGGL((attn_combine2_kernel<D>), grid, blk, 0, st, a);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(a.S + 128 + 8) * sizeof(float);
     hipLaunchKernelGGL((attn_combine_kernel<D>), grid, blk, lds, st, a);
     return hipGetLastError();

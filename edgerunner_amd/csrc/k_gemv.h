@@ -123,17 +123,31 @@ __global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
     const int slice = (KS == 1) ? 0 : wid;                 // K-slice this wave reduces
     const int row0 = (KS == 1) ? (blockIdx.x * ER_NWAVES + wid) * RW : blockIdx.x * RW;
 
-    // ---------------- issue this wave's weight loads first: they do not depend on the prologue, so the
-    // HBM round trip (~1-2 us) overlaps the LayerNorm reductions instead of following them
-    f32x4 w[RW][J];
+    // ---------------- loads, in the order their consumers run.  Vector loads complete in issue order (vmcnt), so the
+    // small prologue / epilogue operands go FIRST and the weight stream behind them: the LayerNorm reductions then
+    // overlap the weights' HBM round trip instead of waiting for the last weight byte (round 1 issued the weights
+    // first and every wave sat in s_waitcnt until the whole stream had landed before it could touch x).
+    float v[NB][PT];
+    float v2[PRO == PRO_EMBED ? NB : 1][PT];   // PRO_EMBED: position rows (added after the weight loads are out)
+    float lw[PT], lb[PT];
+    if (PRO == PRO_EMBED) {
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int row = min(row0 + r, a.N - 1);            // clamp: out-of-range rows are loaded but never stored
-        const f32x4* wr = reinterpret_cast<const f32x4*>(reinterpret_cast<const WT*>(a.W) + (long long)row * K + slice * SL);
+        for (int b = 0; b < NB; ++b) {
+            const float* e = a.embd + (long long)a.tok[b] * K;
+            const float* p = a.posemb + (long long)a.pos[b] * K;
 #pragma unroll
-        for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
+            for (int i = 0; i < PT; ++i) { v[b][i] = e[tid + i * ER_WG]; v2[b][i] = p[tid + i * ER_WG]; }
+        }
+    } else if (PRO == PRO_LN) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float* x = a.xin + (long long)b * K;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) v[b][i] = x[tid + i * ER_WG];
+        }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG]; }
     }
-
     // epilogue operands of the (row, batch) pairs this thread will finish
     EpiPre pre[RW][NB];
     if (KS == 1) {
@@ -145,43 +159,43 @@ __global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
         const int t = min(tid, RW * NB - 1);
         pre[0][0] = gemv_epi_prefetch<EPI>(a, row0 + t / NB, t % NB);
     }
+    f32x4 w[RW][J];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = min(row0 + r, a.N - 1);            // clamp: out-of-range rows are loaded but never stored
+        const f32x4* wr = reinterpret_cast<const f32x4*>(reinterpret_cast<const WT*>(a.W) + (long long)row * K + slice * SL);
+#pragma unroll
+        for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);         // keep the whole stream issued before the prologue arithmetic
 
     // ---------------- prologue: build the input vector(s) in LDS (PRO_NONE reads them straight into the
     // dot-product register layout below: no staging, no barrier)
 #pragma unroll
     for (int b = 0; b < NB && PRO != PRO_NONE; ++b) {
-        float v[PT];
         if (PRO == PRO_EMBED) {
-            const float* e = a.embd + (long long)a.tok[b] * K;
-            const float* p = a.posemb + (long long)a.pos[b] * K;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) v[i] = e[tid + i * ER_WG] + p[tid + i * ER_WG];
-        } else {
-            const float* x = a.xin + (long long)b * K;
-#pragma unroll
-            for (int i = 0; i < PT; ++i) v[i] = x[tid + i * ER_WG];
+            for (int i = 0; i < PT; ++i) v[b][i] += v2[b][i];
         }
         if (PRO == PRO_LN) {
+            // each reduction has its own LDS slot, so it costs one barrier instead of two (same summation order as block_sum)
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) s += v[i];
-            const float mean = block_sum(s, red) / (float)K;
+            for (int i = 0; i < PT; ++i) s += v[b][i];
+            const float mean = block_sum_slot(s, red + 8 * b) / (float)K;
             float s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) { const float d = v[i] - mean; s2 = fmaf(d, d, s2); }
-            const float var = block_sum(s2, red) / (float)K;
+            for (int i = 0; i < PT; ++i) { const float d = v[b][i] - mean; s2 = fmaf(d, d, s2); }
+            const float var = block_sum_slot(s2, red + 8 * b + 4) / (float)K;
             const float rstd = 1.0f / sqrtf(var + a.eps);
 #pragma unroll
-            for (int i = 0; i < PT; ++i) {
-                const int c = tid + i * ER_WG;
-                v[i] = (v[i] - mean) * rstd * a.ln_w[c] + a.ln_b[c];
-            }
+            for (int i = 0; i < PT; ++i) v[b][i] = (v[b][i] - mean) * rstd * lw[i] + lb[i];
         }
 #pragma unroll
-        for (int i = 0; i < PT; ++i) xs[b * K + tid + i * ER_WG] = v[i];
+        for (int i = 0; i < PT; ++i) xs[b * K + tid + i * ER_WG] = v[b][i];
         if (PRO != PRO_NONE && a.hout != nullptr && blockIdx.x == 0) {
 #pragma unroll
-            for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * ER_WG] = v[i];
+            for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * ER_WG] = v[b][i];
         }
     }
     if (PRO != PRO_NONE) __syncthreads();
