@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """Benchmark of the ArAE decode hot path on MI355X (contract: see the task's bench.py section).
 
-One "step" = one full pass of the hot path for one synthetic point cloud per GPU:
+One "step" = one full pass of the hot path for the synthetic point clouds of one batch per GPU:
 encode_cond (point encoder) -> 2050-token prefill -> T greedy tokens with the device-side
-grammar head (LMM.generate; reference core/models.py:204-303).  Workload = BASELINE.json
+grammar head (LMM.generate; reference core/models.py:204-303).  Default workload = BASELINE.json
 configs[1]: ArAE (24 layers, 1536 wide) random-init, batch 1, greedy, test_num_face=1000,
 T = 4*num_faces = 4000 new tokens with EOS suppressed until T, 4096-point cloud, exact fp32
 mode (the mode whose greedy ids are bit-exact vs the reference CPU path).
+``--batch-per-gpu 32`` is BASELINE configs[3]'s shard (256 clouds over 8 GPUs = 32 per GPU).
 
-N > 1: one process per GPU (torchrun), every rank generates for its own cloud (weak
-scaling: independent samples, full weight replica per GPU, no data-path collective) and the
-token streams are all-gathered once per step over RCCL.  value = total tokens / max-over-ranks time.
+N > 1: one process per GPU.  ``python bench.py --gpus N`` launches the N ranks itself (re-executes under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``) unless it already runs
+inside such a launch (WORLD_SIZE set, e.g. by the driver's own torchrun line).  Every rank generates for its own
+clouds (weak scaling: independent samples, full weight replica per GPU, no data-path collective) and the token
+streams are all-gathered once per step over RCCL.  value = total tokens / max-over-ranks time.
+
+``--dry-run`` replaces the GPU work by fabricated token streams (gloo on CPU): it exercises the launch, sharding,
+gather, barrier and max-over-ranks plumbing and prints the same JSON shape with ``"dry_run": true``.
 """
 from __future__ import annotations
 
@@ -18,11 +24,12 @@ import argparse
 import dataclasses
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,33 +37,69 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 W_ELEMS = 680_752_128          # streamed weight elements per token
 KV_ELEMS_PER_POS = 73_728      # 2 * 24 * 1536
+PREFIX = 2050                  # 2049 condition tokens + BOS
 LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "out_proj_gemv": 24, "fc1_gemv": 24,
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_hbm_summary.json")
 
 
-# kernel names as rocprofv3 reports them (scripts/pmc_summary.py::short); gemv_kernel<WT, KS, NB, RW, PRO, EPI>
-KIND_TO_KERNEL = {"qkv_gemv": "gemv_kernel<float, 1, 1, 1, 1, 3>", "attn_decode": "attn_decode_kernel<float, 96, 4>",
-                  "attn_combine": "attn_combine_kernel<96>", "out_proj_gemv": "gemv_kernel<float, 1, 1, 1, 0, 2>",
-                  "fc1_gemv": "gemv_kernel<float, 1, 1, 2, 1, 1>", "fc2_gemv": "gemv_kernel<float, 4, 1, 2, 0, 2>",
-                  "lm_head_gemv": "gemv_kernel<float, 1, 1, 1, 1, 0>", "sample_head": "sample_head_kernel"}
-# the same kernels under the names of the first PMC pass of this round (before the fp16 templates were added)
-KIND_TO_KERNEL_OLD = {"qkv_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 3>", "attn_decode": "attn_decode_f32_kernel<96, 4>",
-                      "attn_combine": "attn_combine_f32_kernel<96, 4>", "out_proj_gemv": "gemv_f32_kernel<6, 1, 1, 1, 0, 2>",
-                      "fc1_gemv": "gemv_f32_kernel<6, 1, 1, 2, 1, 1>", "fc2_gemv": "gemv_f32_kernel<6, 4, 1, 2, 0, 2>",
-                      "lm_head_gemv": "gemv_f32_kernel<6, 1, 1, 1, 1, 0>", "sample_head": "sample_head_kernel"}
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=1, help="clouds per generate() call per GPU (32 = configs[3] shard)")
+    ap.add_argument("--num-face", type=int, default=1000)
+    ap.add_argument("--tokens", type=int, default=None, help="new tokens per sample (default 4*num_face)")
+    ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--resume-len", type=int, default=0,
+                    help="extra teacher-given tokens appended to the prefix (resume_ids): starts the decode at a longer "
+                         "context; used by the PMC passes to measure attention traffic at the run's mean context length")
+    ap.add_argument("--cpu-steps", type=int, default=120, help="decode steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--precision", choices=("fp32", "fp16"), default="fp32",
+                    help="fp32 = exact mode (the mode whose ids are bit-exact vs the CPU path; default); fp16 = fast mode")
+    ap.add_argument("--no-fast-extra", action="store_true", help="skip the additional fp16 fast-mode / batch-32 measurements")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: fabricated streams through the same multi-rank plumbing")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
 
 
-def pmc_traffic(kind):
-    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_summary.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes;
-    separate --pmc runs, see scripts/gpu_pmc.sh).  Counters cannot be read inside the timed process."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_summary.json")
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a distributed launch: start the N ranks (one process per GPU)."""
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(kind, kernel_names, at_len):
+    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_hbm_summary.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes; separate --pmc runs, scripts/gpu_pmc.sh).  Counters cannot
+    be read inside the timed process.  The attention passes run at a recorded context length (the PMC run starts its
+    decode at --resume-len); its bytes are scaled linearly to `at_len` keys, the length `bytes_per_launch` is quoted at."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
     try:
-        ks = json.load(open(path))["kernels"]
-        k = ks.get(KIND_TO_KERNEL[kind]) or ks[KIND_TO_KERNEL_OLD[kind]]
-        note = " (attention measured at context 2050..2062: 2*L*1536*4 B algorithmic there)" if kind == "attn_decode" else ""
-        return {"bytes": round(k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)),
-                "source": "profiles/r01_pmc_hbm_summary.json" + note}
+        doc = json.load(open(path))
+        ks = doc["kernels"]
+        k = next(ks[n] for n in kernel_names if n in ks)
+        b = k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)
+        note = ""
+        if kind == "attn_decode":
+            l_pmc = float(doc.get("attention_context_len_mean", 0) or 0)
+            if l_pmc > 0:
+                b = b * at_len / l_pmc
+                note = f" (attention measured at mean context {l_pmc:.0f}, scaled x{at_len / l_pmc:.4f} to {at_len} keys)"
+        return {"bytes": round(b), "source": PMC_SUMMARY + note}
     except Exception:
         return {}
 
@@ -70,6 +113,7 @@ def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
     restatement that is bit-identical to the reference's own modules, see oracle/) on a bounded
     sample of the same workload: encode + prefill + the first decode steps (at most T_sample
     steps or budget_s seconds of decoding, whichever comes first)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import arae_oracle as O
     from edgerunner_amd import weights as W
@@ -120,21 +164,61 @@ def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--num-face", type=int, default=1000)
-    ap.add_argument("--tokens", type=int, default=None, help="new tokens per sample (default 4*num_face)")
-    ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--points", type=int, default=4096)
-    ap.add_argument("--cpu-steps", type=int, default=120, help="decode steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=("fp32", "fp16"), default="fp32",
-                    help="fp32 = exact mode (the mode whose ids are bit-exact vs the CPU path; default); fp16 = fast mode")
-    ap.add_argument("--no-fast-extra", action="store_true", help="skip the additional fp16 fast-mode measurement")
-    args = ap.parse_args()
+def kernel_names(precision, batched):
+    """rocprofv3 names of the decode kernels per kind for this build (scripts/roofline_from_rocprof.py uses the same table)."""
+    wt = "float" if precision == "fp32" else "_Float16"
+    if batched:
+        return {"attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
+    rw = (1, 2, 2, 1) if precision == "fp32" else (2, 4, 4, 2)
+    return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, {rw[0]}, 1, 3>"],
+            "attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>", f"attn_decode_kernel<{wt}, 96, 4>"],
+            "attn_combine": ["attn_combine2_kernel<96>", "attn_combine_kernel<96>"],
+            "out_proj_gemv": [f"gemv_kernel<{wt}, 1, 1, {rw[3]}, 0, 2>"],
+            "fc1_gemv": [f"gemv_kernel<{wt}, 1, 1, {rw[1]}, 1, 1>"], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, {rw[2]}, 0, 2>"],
+            "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, {2 if precision == 'fp16' else 1}, 1, 0>"], "sample_head": ["sample_head_kernel"]}
 
+
+def dry_run(args):
+    """Multi-rank plumbing without a GPU: gloo, fabricated streams, same gather / barrier / max-over-ranks / JSON."""
+    from edgerunner_amd import dist as D
+    rank, world, _ = D.init_process_group(backend="gloo")
+    B, T = args.batch_per_gpu, args.tokens or 4 * args.num_face
+    n_items = world * B
+
+    def one_step(k):
+        mine = D.shard_indices(n_items, rank, world)
+        streams = [np.full(T, 6 + (i + k) % 500, dtype=np.int64) for i in mine]
+        got = D.gather_token_streams(streams, n_items)
+        assert len(got) == n_items and all(int(g[0]) == 6 + (i + k) % 500 for i, g in enumerate(got))
+
+    for w in range(args.warmup):
+        one_step(-1 - w)
+    D.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "mesh tokens/sec (whole node), ArAE greedy test_num_face=1000", "dry_run": True,
+                          "value": round(world * B * T * args.steps / max(elapsed, 1e-9), 2), "unit": "tokens/s",
+                          "n_gpus": world, "world_size_seen": world, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "data": "fabricated (dry run: no GPU work)",
+                          "config": {"workload": f"dry run: {B} fabricated stream(s) of {T} ids per rank", "batch_per_gpu": B}}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if args.dry_run:
+        return dry_run(args)
+
+    import torch
     from edgerunner_amd import dist as D
     from edgerunner_amd import weights as W
     from edgerunner_amd.models import LMM
@@ -142,18 +226,19 @@ def main():
 
     rank, world, local = D.init_process_group()
     if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; reporting the world size actually running", file=sys.stderr)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path (see --dry-run)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     T = args.tokens or 4 * args.num_face
+    B = args.batch_per_gpu
     opt = dataclasses.replace(config_defaults["ArAE"], num_layers=args.layers, generate_mode="greedy")
 
     t0 = time.time()
     lmm = LMM(opt, dev, precision=args.precision)
     esz = 4 if args.precision == "fp32" else 2
-    keep_sd = rank == 0 and world == 1 and args.cpu_steps > 0
+    keep_sd = rank == 0 and world == 1 and args.cpu_steps > 0 and B == 1
     sd = {}
     def items():
         for k, t in W.iter_state_dict(opt, 0, "perturbed"):
@@ -163,12 +248,20 @@ def main():
     lmm.mesh_decoder.load_state_iter(items(), strict=True)
     if rank == 0:
         print(f"[bench] weights generated + loaded in {time.time() - t0:.1f}s", file=sys.stderr)
+    resume = None
+    if args.resume_len > 0:      # legal LR_ABSCO prefix: BOM + 9 coordinates, then (L/R + 3 coordinates) groups
+        body = [5] + [6 + (i * 37) % 512 for i in range(9)]
+        while len(body) < args.resume_len:
+            body += [3 + (len(body) // 4) % 2] + [6 + ((len(body) + i) * 53) % 512 for i in range(3)]
+        resume = torch.tensor([body[: args.resume_len]] * B, dtype=torch.long)
+    n_items = world * B
 
     def one_step(step_idx):
-        pc = W.synthetic_point_cloud(step_idx * world + rank, args.points).to(dev)      # resident in HBM
-        _, toks = lmm.generate(pc, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
-        streams = D.gather_token_streams([toks[0]], world, device=dev)
-        assert len(streams) == world and all(len(s) == T for s in streams)
+        mine = D.shard_indices(n_items, rank, world)        # cloud index i runs on rank i mod world
+        pcs = torch.cat([W.synthetic_point_cloud(step_idx * n_items + i, args.points) for i in mine]).to(dev)   # resident in HBM
+        _, toks = lmm.generate(pcs, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T, resume_ids=resume)
+        streams = D.gather_token_streams([t[args.resume_len:] for t in toks], n_items, device=dev)
+        assert len(streams) == n_items and all(len(s) == T for s in streams)
         return lmm.mesh_decoder.last_decode_ms
 
     def log(msg):
@@ -187,24 +280,43 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t_start, dev)
     log(f"timed region done: {elapsed:.2f}s")
 
-    total_tokens = world * args.steps * T
+    total_tokens = n_items * args.steps * T
     value = total_tokens / elapsed
-    decode_only = world * T / (D.max_over_ranks(float(np.mean(dec_ms)), dev) / 1e3)
+    decode_only = n_items * T / (D.max_over_ranks(float(np.mean(dec_ms)), dev) / 1e3)
 
-    # ---- roofline of the dominant decode kernel, measured live with HIP events on the launch stream
-    prof = lmm.mesh_decoder.profile_decode_kernels(repeats=4)      # at the final context length (2050 + T)
+    # ---- roofline of the dominant decode kernel over the run that was timed.  The context grows linearly from
+    # L0 = prefix + 1 to L0 + T - 1 and every decode kernel's duration is affine in the context length, so the
+    # run-average duration of a kernel (what `rocprofv3 --stats` reports for the same command) is its duration at the
+    # MEAN context length: the sweep below runs the attention kernels at exactly that length (hipGraph replay of the 24
+    # launches of a kind, HIP events on the launch stream, all 24 layers' weights so nothing is cache-resident).
+    # scripts/roofline_from_rocprof.py recomputes `frac` from profiles/*_kernel_stats.csv and checks the two agree.
+    L0 = PREFIX + args.resume_len
+    mean_L = L0 + (T - 1) / 2.0 + 1.0             # keys visible to the step (incl. the token being fed), run average
+    L_ref = int(round(mean_L))
+    prof = lmm.mesh_decoder.profile_decode_kernels(repeats=6, context_len=L_ref, use_graph=True)
+    ends = {}
+    for tag, L in (("first", L0 + 1), ("last", L0 + T)):
+        p = lmm.mesh_decoder.profile_decode_kernels(repeats=3, context_len=L, use_graph=True)
+        ends[tag] = {"context_len": L, "attn_decode_us": round(p["attn_decode"]["avg_us"], 3),
+                     "attn_combine_us": round(p["attn_combine"]["avg_us"], 3)}
     log("kernel sweep done")
     per_token_us = {k: v["avg_us"] * LAUNCHES_PER_TOKEN[k] for k, v in prof.items()}
     dom = max(per_token_us, key=per_token_us.get)
     ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
-    mean_L = 2050 + (T - 1) / 2.0
-    bytes_per_token = W_ELEMS * esz + KV_ELEMS_PER_POS * (mean_L + 1) * esz
-    traffic = pmc_traffic(dom)
+    bytes_per_token = W_ELEMS * esz / B + KV_ELEMS_PER_POS * mean_L * esz
+    names = kernel_names(args.precision, B > 4)
+    traffic = pmc_traffic(dom, names.get(dom, []), L_ref)
+    layer_us = sum(prof[k]["avg_us"] for k in ("qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv", "fc1_gemv", "fc2_gemv"))
     roofline = {
-        "bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"),
+        "bound": "hbm", "kernel": dom, "kernel_name": (names.get(dom) or ["?"])[0], "achieved": round(ach, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+        "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"),
         "bytes_per_launch": prof[dom]["bytes"], "avg_us_per_launch": round(prof[dom]["avg_us"], 3),
-        "context_len_at_measurement": 2050 + T,
+        "context_len_at_measurement": L_ref,
+        "note": "run-average: duration and algorithmic bytes of one launch at the mean context length of the timed run "
+                f"(contexts {L0 + 1}..{L0 + T}); reproduce with scripts/roofline_from_rocprof.py on profiles/r02_*_kernel_stats.csv",
+        "context_ends": ends,
+        "per_layer_kernel_sum_us": round(layer_us, 2),
         "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1),
                         "us_per_token": round(per_token_us[k], 2)} for k, v in prof.items()},
         "whole_step": {"bytes_per_token": bytes_per_token,
@@ -212,21 +324,23 @@ def main():
                        "frac": round(decode_only / world * bytes_per_token / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
+    cfg_name = "BASELINE configs[1]" if B == 1 else (f"BASELINE configs[3] shard ({B} clouds per GPU)" if B == 32 else f"batch {B} per GPU")
     out = {
         "metric": "mesh tokens/sec (whole node), ArAE greedy test_num_face=1000",
-        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "world_size_seen": world, "steps": args.steps,
+        "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16 storage / f32 accumulate", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: ArAE random-init (seeded synthetic checkpoint), batch 1 per GPU, greedy, "
+        "config": {"workload": f"{cfg_name}: ArAE random-init (seeded synthetic checkpoint), batch {B} per GPU, greedy, "
                                f"test_num_face={args.num_face}, {T} new tokens (EOS suppressed until T), "
-                               f"{args.points}-point synthetic cloud; step = encode_cond + 2050-token prefill + {T}-token decode"
+                               f"{args.points}-point synthetic cloud; step = encode_cond + {L0}-token prefill + {T}-token decode"
                                f"{' + RCCL all-gather of token streams' if world > 1 else ''}",
-                   "layers": args.layers, "hidden": 1536, "heads": 16, "tokens_per_sample": T,
+                   "layers": args.layers, "hidden": 1536, "heads": 16, "tokens_per_sample": T, "batch_per_gpu": B,
                    "parallelism": f"dp{world} (independent samples, full replica per GPU)"},
         "decode_only_tokens_per_s": round(decode_only, 2),
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and args.precision == "fp32" and not args.no_fast_extra:
+    if rank == 0 and world == 1 and B == 1 and args.precision == "fp32" and not args.no_fast_extra:
         # secondary figure (not `value`): the same workload in the fp16-storage fast mode, the reference's GPU dtype
         del lmm
         torch.cuda.empty_cache()
@@ -235,7 +349,7 @@ def main():
         pc = W.synthetic_point_cloud(0, args.points).to(dev)
         for _ in range(2):
             fast.generate(pc, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
-        fb = W_ELEMS * 2 + KV_ELEMS_PER_POS * (mean_L + 1) * 2
+        fb = W_ELEMS * 2 + KV_ELEMS_PER_POS * mean_L * 2
         ftok = T / (fast.mesh_decoder.last_decode_ms / 1e3)
         out["fast_mode_fp16"] = {"decode_only_tokens_per_s": round(ftok, 2), "bytes_per_token": fb,
                                  "hbm_frac": round(ftok * fb / 1e9 / HBM_PEAK_GBS, 4),
@@ -256,7 +370,7 @@ def main():
             out["batch32_fp16"] = {"error": repr(e)[:200]}
         del fast
         log("fast-mode + batch-32 passes done")
-    if rank == 0 and world == 1 and args.cpu_steps > 0:
+    if keep_sd:
         out["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_steps, args.points)
         out["gpu_over_cpu"] = round(out["decode_only_tokens_per_s"] / out["cpu_baseline"]["value"], 1)
     if rank == 0:

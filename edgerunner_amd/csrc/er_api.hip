@@ -110,6 +110,7 @@ struct er_ctx {
     float* skpart = nullptr;  // split-K partials of the batched fc2
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
+    int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
@@ -117,6 +118,7 @@ struct er_ctx {
     Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp;
 };
 
+constexpr int ER_MAX_BATCH = 1023;   // h_pinned holds B ints + one flag
 constexpr int NBM = 32;   // batch rows per pass of the matrix-core decode projections (k_gemv_mfma.h)
 
 static int ensure(Buf& b, size_t n) {
@@ -464,6 +466,7 @@ static int make_tiled_weights(er_ctx* c) {
 // ------------------------------------------------------------------------------------ KV cache / workspace
 extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     if (!c || batch <= 0 || max_len <= 0) return fail(ER_ERR_INVALID, "er_kv_reserve: bad argument");
+    if (batch > ER_MAX_BATCH) return fail(ER_ERR_UNSUPPORTED, "er_kv_reserve: batch %d > %d (host staging buffers are sized for %d rows)", batch, ER_MAX_BATCH, ER_MAX_BATCH);
     HIPCHK(hipSetDevice(c->device));
     const er_config& g = c->cfg;
     if (max_len > g.max_positions)
@@ -495,7 +498,7 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
     c->st.tok = sb; c->st.pos = sb + b; c->st.counter = sb + 2 * b; c->st.ngen = sb + 3 * b;
-    c->st.unfinished = sb + 4 * b; c->st.eos_step = sb + 5 * b; c->st.base_pos = sb + 6 * b; c->st.n_unfinished = sb + 7 * b;
+    c->st.unfinished = sb + 4 * b; c->st.eos_step = sb + 5 * b; c->st.base_pos = sb + 6 * b; c->st.n_unfinished = sb + 7 * b; c->st.error = sb + 7 * b + 1;
     HIPCHK(hipMalloc(&c->d_params, sizeof(DecodeParamsDev)));
     HIPCHK(hipMalloc(&c->d_ids_tmp, b * sizeof(int)));
     HIPCHK(hipMalloc(&c->d_out_ids, b * (size_t)Lcap * sizeof(long long)));
@@ -611,7 +614,7 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     a.vcache = (char*)c->vc + (long long)layer * c->kv_lstride * c->kv_esz;
     a.chunk = attn_chunk(c->attn_steps, c->fast);
     a.pos = c->st.pos;
-    a.fixed_len = 0;
+    a.fixed_len = c->prof_len;
     a.len_dev = nullptr;
     a.part = c->part;
     a.out = c->abuf;
@@ -966,7 +969,6 @@ extern "C" int er_feed(er_ctx* c, const int32_t* ids, void* stream) {
     hipStream_t st = pick(c, stream);
     HIPCHK(hipStreamSynchronize(st));
     ERCHK(check_room(c, 1));
-    if (c->B > 1024) return fail(ER_ERR_UNSUPPORTED, "batch > 1024");
     for (int b = 0; b < c->B; ++b) {
         if (ids[b] < 0 || ids[b] >= c->cfg.vocab_size) return fail(ER_ERR_INVALID, "token id %d out of range", ids[b]);
         c->h_pinned[b] = ids[b];
@@ -985,7 +987,7 @@ __global__ void fill_i64_kernel(long long* p, long long n, long long v) {
 }
 __global__ void reset_gen_kernel(GenState st, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) *st.n_unfinished = B;
+    if (b == 0) { *st.n_unfinished = B; *st.error = 0; }
     if (b >= B) return;
     st.counter[b] = 0; st.unfinished[b] = 1; st.eos_step[b] = -1;
 }
@@ -1047,8 +1049,11 @@ extern "C" int er_decode(er_ctx* c, const er_decode_params* p, int64_t* out_ids,
     HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)T * sizeof(long long), c->d_out_ids, (size_t)c->Lcap * sizeof(long long),
                             (size_t)T * sizeof(long long), B, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(c->h_pinned, c->st.eos_step, B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_pinned + B, c->st.error, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&c->last_decode_ms, c->ev0, c->ev1));
+    if (c->h_pinned[B] != 0)
+        return fail(ER_ERR_INVALID, "er_decode: a row had no finite candidate score (non-finite logits); HF would raise in multinomial/argmax");
     (void)all_done;
     // HF returns as many columns as steps it ran: it stops right after the step in which the last row emits EOS
     int last = -1;
@@ -1069,7 +1074,23 @@ extern "C" int er_last_decode_ms(er_ctx* c, float* ms) {
 }
 
 // ------------------------------------------------------------------------------------ per-kernel timing
+static int profile_impl(er_ctx* c, int repeats, int use_graph, float* avg_us, double* bytes, void* stream);
+
 extern "C" int er_profile_decode_kernels(er_ctx* c, int repeats, float* avg_us, double* bytes, void* stream) {
+    return er_profile_decode_kernels_at(c, repeats, 0, 0, avg_us, bytes, stream);
+}
+
+extern "C" int er_profile_decode_kernels_at(er_ctx* c, int repeats, int context_len, int use_graph, float* avg_us, double* bytes,
+                                            void* stream) {
+    if (!c) return fail(ER_ERR_INVALID, "er_profile_decode_kernels: bad argument");
+    if (context_len < 0 || context_len > c->Lcap) return fail(ER_ERR_CAPACITY, "profile: context_len %d outside the reserved cache (%d)", context_len, c->Lcap);
+    c->prof_len = context_len;
+    const int rc = profile_impl(c, repeats, use_graph, avg_us, bytes, stream);
+    c->prof_len = 0;
+    return rc;
+}
+
+static int profile_impl(er_ctx* c, int repeats, int use_graph, float* avg_us, double* bytes, void* stream) {
     if (!c || !avg_us || !bytes || repeats <= 0) return fail(ER_ERR_INVALID, "er_profile_decode_kernels: bad argument");
     if (!c->have_hidden) return fail(ER_ERR_INVALID, "profile: call er_prefill first");
     HIPCHK(hipSetDevice(c->device));
@@ -1078,7 +1099,7 @@ extern "C" int er_profile_decode_kernels(er_ctx* c, int repeats, float* avg_us, 
     const int B = c->B, H = g.hidden_dim, I = g.intermediate_dim, nl = g.num_layers, V = g.vocab_size;
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpy(c->h_pinned, c->st.pos, sizeof(int), hipMemcpyDeviceToHost));
-    const double len = (double)c->h_pinned[0] + 1.0;
+    const double len = c->prof_len > 0 ? (double)c->prof_len : (double)c->h_pinned[0] + 1.0;
     // save the state the sweep scribbles on
     std::vector<float> save_y((size_t)B * H);
     HIPCHK(hipMemcpy(save_y.data(), c->ypre, save_y.size() * 4, hipMemcpyDeviceToHost));
@@ -1106,12 +1127,26 @@ extern "C" int er_profile_decode_kernels(er_ctx* c, int repeats, float* avg_us, 
     for (int kind = 0; kind < ER_NUM_KERNEL_KINDS; ++kind) {
         const bool per_layer = kind <= 5;
         // warm-up + timed sweeps
+        hipGraphExec_t gexec = nullptr;
+        if (use_graph && per_layer) {     // the nl launches of this kind as one replayable graph (what the generation loop replays)
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeRelaxed));
+            hipError_t e = hipSuccess;
+            for (int l = 0; l < nl && e == hipSuccess; ++l) e = launch_kind(c, kind, l, c->own_stream, dummy_ids, 8);
+            hipError_t e2 = hipStreamEndCapture(c->own_stream, &graph);
+            if (e != hipSuccess || e2 != hipSuccess) { if (graph) hipGraphDestroy(graph); return fail(ER_ERR_HIP, "profile: graph capture failed"); }
+            HIPCHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+        }
         for (int pass = 0; pass < 2; ++pass) {
             const int reps = pass == 0 ? 1 : repeats;
             if (pass == 1) HIPCHK(hipEventRecord(c->ev0, st));
             int launches = 0;
             for (int r = 0; r < reps; ++r) {
-                if (per_layer) {
+                if (gexec) {
+                    HIPCHK(hipGraphLaunch(gexec, st));
+                    launches += nl;
+                } else if (per_layer) {
                     // ER_PROF_LAYERS=n restricts the sweep to the first n layers (cache-residency experiments)
                     const char* pl = getenv("ER_PROF_LAYERS");
                     const int span = (pl && atoi(pl) > 0 && atoi(pl) < nl) ? atoi(pl) : nl;
@@ -1134,6 +1169,7 @@ extern "C" int er_profile_decode_kernels(er_ctx* c, int repeats, float* avg_us, 
                 avg_us[kind] = ms * 1000.0f / (float)launches;
             }
         }
+        if (gexec) hipGraphExecDestroy(gexec);
     }
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpy(c->ypre, save_y.data(), save_y.size() * 4, hipMemcpyHostToDevice));
@@ -1291,7 +1327,7 @@ extern "C" int er_k_sample_head(const float* logits, const er_decode_params* p, 
     HIPCHK(hipMemcpy(sb, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
     GenState s{};
     s.tok = sb; s.pos = sb + b; s.counter = sb + 2 * b; s.ngen = sb + 3 * b; s.unfinished = sb + 4 * b;
-    s.eos_step = sb + 5 * b; s.base_pos = sb + 6 * b; s.n_unfinished = sb + 7 * b;
+    s.eos_step = sb + 5 * b; s.base_pos = sb + 6 * b; s.n_unfinished = sb + 7 * b; s.error = sb + 7 * b + 1;
     DecodeParamsDev dp{};
     dp.mode = p->mode; dp.top_k = p->top_k; dp.grammar = p->grammar; dp.max_new = step + 1; dp.min_new = p->min_new_tokens;
     dp.eos = eos; dp.pad = pad; dp.vocab = vocab;

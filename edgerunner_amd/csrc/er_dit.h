@@ -400,6 +400,9 @@ extern "C" int er_dit_sample(er_dit_ctx* c, const float* cond, int B, int M, flo
                              int init_step, void* stream) {
     if (!c || !cond || !latents || B <= 0 || M <= 0 || steps <= 0 || steps > 1000 || init_step < 0 || init_step >= steps)
         return fail(ER_ERR_INVALID, "er_dit_sample: bad argument");
+    if ((steps - 1) * (1000 / steps) + 1 >= 1000)   // leading spacing + offset 1: the first timestep must index the 1000-entry table
+        return fail(ER_ERR_INVALID, "er_dit_sample: %d steps put the first timestep at %d (>= 1000 training steps)", steps,
+                    (steps - 1) * (1000 / steps) + 1);
     ERCHK(er_dit_finalize_weights(c));
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;

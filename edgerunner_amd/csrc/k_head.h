@@ -33,6 +33,7 @@ struct GenState {              // per-row arrays, all device
     int* eos_step;             // step index at which EOS was emitted (-1)
     int* base_pos;             // prefill length (position of the first generated token's forward)
     int* n_unfinished;         // scalar: rows still running
+    int* error;                // scalar: set when a row had no finite candidate score (non-finite logits)
 };
 
 // Philox4x32-10 (Salmon et al. 2011): counter-based, so a draw is a pure function of
@@ -129,8 +130,12 @@ __global__ __launch_bounds__(ER_WG) void sample_head_kernel(const float* logits,
     for (int w = 1; w < ER_NWAVES; ++w)
         if (red[w] > gmax || (red[w] == gmax && redi[w] < gidx)) { gmax = red[w]; gidx = redi[w]; }
     int chosen = gidx;
+    // every masked score is NaN or -inf (fp16 overflow upstream, corrupt weights): HF would raise inside
+    // torch.multinomial; here the row is closed with EOS and the error flag makes er_decode fail loudly
+    const bool no_candidate = gidx < 0 || gidx >= V || !(gmax > -INFINITY);
+    if (no_candidate) chosen = P.eos;
 
-    if (P.mode == 1) {   // sample: TopK(top_k) -> softmax -> categorical
+    if (P.mode == 1 && !no_candidate) {   // sample: TopK(top_k) -> softmax -> categorical
         // k-th largest value counting duplicates: remove one maximum k-1 times (wave 0, scores in registers)
         if (wid == 0) {
             constexpr int MAXPL = ER_HEAD_MAX_VOCAB / 64;   // scores of the whole vocabulary in wave 0's registers
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(ER_WG) void sample_head_kernel(const float* logits,
                 const float u = (float)(r[0] >> 8) * (1.0f / 16777216.0f);
                 const float target = u * total;
                 float acc = 0.f;
-                int pick = cand_i[base - 1];
+                int pick = base > 0 ? cand_i[base - 1] : P.eos;
                 for (int c = 0; c < base; ++c) {
                     acc += cand_e[c];
                     if (acc > target) { pick = cand_i[c]; break; }
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(ER_WG) void sample_head_kernel(const float* logits,
     }
 
     if (tid == 0) {
+        if (no_candidate && running) *st.error = 1;
         int next = running ? chosen : P.pad;
         out_ids[(long long)b * out_ld + t] = (long long)next;
         st.tok[b] = next;
@@ -216,7 +222,7 @@ __global__ void force_token_kernel(const int* ids_dev, GenState st, int B) {
 
 __global__ void init_state_kernel(GenState st, int B, int base_pos) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) *st.n_unfinished = B;
+    if (b == 0) { *st.n_unfinished = B; *st.error = 0; }
     if (b >= B) return;
     st.tok[b] = 0; st.pos[b] = base_pos; st.counter[b] = 0; st.ngen[b] = 0;
     st.unfinished[b] = 1; st.eos_step[b] = -1; st.base_pos[b] = base_pos;

@@ -38,14 +38,15 @@ class _DecoderModel:
 
 
 class LMM:
-    def __init__(self, opt, device="cuda:0", precision: str = "fp32"):
-        """precision: 'fp32' = exact mode (fp32 weights + KV; greedy ids bit-exact vs the CPU path) or
-        'fp16' = fast mode (decoder matrices and KV cache stored in fp16 like the reference's
-        ``model.half()`` GPU path, fp32 accumulate)."""
+    def __init__(self, opt, device="cuda:0", precision: Optional[str] = "fp32"):
+        """precision: 'fp32' = exact mode (fp32 weights + KV; greedy ids bit-exact vs the CPU path), 'fp16' = fast mode
+        (decoder matrices and KV cache stored in fp16 like the reference's ``model.half()`` GPU path, fp32 accumulate),
+        or None = module style: fp32 until ``.half()`` is called, the native context being created on first use, so
+        that the reference's ``LMM(opt)`` -> ``load_state_dict`` -> ``.half().eval().to(device)`` (infer.py:41-56)
+        selects the fp16 context exactly as it selects fp16 storage there."""
         self.opt = opt
-        if precision not in ("fp32", "fp16"):
+        if precision not in (None, "fp32", "fp16"):
             raise ValueError(precision)
-        self.precision = precision
         if opt.cond_mode == "image":
             raise NotImplementedError("cond_mode='image' (CLIP conditioner) is outside the ArAE decode path")
         if opt.cond_mode == "point" and opt.point_encoder_mode != "embed":
@@ -53,32 +54,87 @@ class LMM:
         self.dims = dims_from_options(opt)
         self.vocab_size = self.dims.vocab_size
         self.device = torch.device(device)
-        dt = torch.float32 if precision == "fp32" else torch.float16
-        self.mesh_decoder = NativeShapeOPT(self.dims, opt, self.device, weight_dtype=dt, kv_dtype=dt)
-        self.mesh_decoder.model = _DecoderModel(self.mesh_decoder)
+        if self.device.type != "cuda":
+            raise native.NativeError("this LMM only runs on a HIP device (cuda:N); there is no CPU fallback")
+        self._dtype = torch.float16 if precision == "fp16" else torch.float32
+        self._dec: Optional[NativeShapeOPT] = None
+        self._sources: List[tuple] = []        # (state_dict reference, strict) of every load_state_dict call, for re-creation
         self.training = False
-        self._dtype_requested = torch.float32
+        if precision is not None:
+            self._materialize()
+
+    # -- native context ------------------------------------------------------------------------
+    @property
+    def precision(self) -> str:
+        return "fp16" if self._dtype == torch.float16 else "fp32"
+
+    def _materialize(self):
+        dec = NativeShapeOPT(self.dims, self.opt, self.device, weight_dtype=self._dtype, kv_dtype=self._dtype)
+        dec.model = _DecoderModel(dec)
+        for sd, strict in self._sources:
+            dec.load_state_dict(sd, strict=strict)
+        dec.direct_loads = False               # everything loaded so far is replayable from self._sources
+        self._dec = dec
+        return dec
+
+    @property
+    def mesh_decoder(self) -> NativeShapeOPT:
+        """The native decoder context (created on first access in module style)."""
+        return self._dec if self._dec is not None else self._materialize()
 
     # -- nn.Module-shaped conveniences so infer.py reads like the reference's ----------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
-        return self.mesh_decoder.load_state_dict(sd, strict=strict)
+        """Returns (missing, unexpected) like nn.Module.load_state_dict.  The dict is kept by reference (no copy) so a
+        later ``.half()`` / ``.float()`` can rebuild the native context in the other storage precision."""
+        self._sources.append((sd, strict))
+        if self._dec is not None:
+            prev = self._dec.direct_loads
+            out = self._dec.load_state_dict(sd, strict=strict)
+            self._dec.direct_loads = prev
+            return out
+        from .weights import tensor_specs
+        want = {k for k, _, _ in tensor_specs(self.dims)}
+        have = {k for k, t in sd.items() if isinstance(t, torch.Tensor)}
+        missing, unexpected = sorted(want - have), sorted(have - want)
+        if strict and (missing or unexpected):
+            raise native.NativeError(f"load_state_dict(strict=True): missing {missing[:5]}, unexpected {unexpected[:5]}")
+        return missing, unexpected
+
+    def _cast(self, dtype):
+        if dtype == self._dtype:
+            return self
+        if self._dec is not None and self._dec.direct_loads:
+            raise native.NativeError(
+                f"LMM.{'half' if dtype == torch.float16 else 'float'}(): this context's weights were streamed directly into "
+                f"the {self.precision} native context (mesh_decoder.load_state_iter / load_state_dict); they cannot be "
+                f"re-stored. Create LMM(opt, device, precision='{'fp16' if dtype == torch.float16 else 'fp32'}') instead.")
+        self._dtype = dtype
+        if self._dec is not None:            # rebuild lazily from the retained checkpoints in the new storage precision
+            self._dec.close()
+            self._dec = None
+        return self
 
     def half(self):
-        # The reference casts to fp16 here (infer.py:56).  Storage precision is fixed when the context is
-        # created - LMM(..., precision='fp16') is the counterpart; the request is only recorded.
-        self._dtype_requested = torch.float16
-        return self
+        """The reference casts to fp16 here (infer.py:56): selects the fp16-storage context (fp32 accumulate)."""
+        return self._cast(torch.float16)
 
     def float(self):
-        self._dtype_requested = torch.float32
-        return self
+        return self._cast(torch.float32)
 
     def eval(self):
         return self
 
     def to(self, device):
-        if torch.device(device).type != "cuda":
+        d = torch.device(device)
+        if d.type != "cuda":
             raise native.NativeError("this LMM only runs on a HIP device")
+        if d.index is not None and self.device.index is not None and d.index != self.device.index:
+            if self._dec is not None and self._dec.direct_loads:
+                raise native.NativeError("LMM.to(): weights were streamed into the context of another device")
+            if self._dec is not None:
+                self._dec.close()
+                self._dec = None
+            self.device = d
         return self
 
     # -- conditioning -------------------------------------------------------------------------

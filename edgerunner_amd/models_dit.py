@@ -27,31 +27,56 @@ def ddim_alphas_cumprod(num_train: int = 1000, beta_start: float = 0.00085, beta
 
 
 class MDiT:
-    def __init__(self, opt, device="cuda:0", clip_layers: int = 32, precision: str = "fp32"):
+    def __init__(self, opt, device="cuda:0", clip_layers: int = 32, precision: Optional[str] = "fp32"):
         """clip_layers: depth of the CLIP ViT image encoder to expect in the checkpoint (32 = ViT-H/14 as in the
-        reference; 0 = no image encoder: get_cond then takes its last_hidden_state directly)."""
+        reference; 0 = no image encoder: get_cond then takes its last_hidden_state directly).
+        precision: 'fp32' (exact), 'fp16' (every Linear on the fp16-input matrix cores, the reference's GPU dtype), or
+        None = module style: fp32 until ``.half()`` is called (reference infer_dit.py:70), context created on first use."""
         self.opt = opt
         self.clip_layers = clip_layers
-        if precision not in ("fp32", "fp16"):
+        if precision not in (None, "fp32", "fp16"):
             raise ValueError(precision)
-        self.precision = precision      # 'fp16': every Linear on the fp16-input matrix cores (the reference's GPU dtype)
+        self._fp16 = precision == "fp16"
+        if getattr(opt, "noise_scheduler_predtype", "v_prediction") != "v_prediction":
+            # the reference forwards this option to DDIMScheduler (core/models_dit.py:91); the device sampler
+            # (ddim_cfg_step_kernel) implements the v-prediction update only - refuse rather than sample wrong latents
+            raise NotImplementedError(f"noise_scheduler_predtype={opt.noise_scheduler_predtype!r}: the DDIM step kernel "
+                                      "implements 'v_prediction' (the released DiT checkpoints' target) only")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise native.NativeError("MDiT needs a HIP device; there is no CPU fallback")
         self.lib = native.load_library()
+        self._ctx_h = C.c_void_p()
+        self._sources = []                 # (state_dict reference, strict): replayed when .half()/.float() re-creates the context
+        self.stream = torch.cuda.Stream(device=self.device)
+        if precision is not None:
+            self._materialize()
+
+    @property
+    def precision(self) -> str:
+        return "fp16" if self._fp16 else "fp32"
+
+    def _materialize(self):
+        opt = self.opt
         cfg = native.ErDitConfig(hidden_dim=opt.dit_hidden_dim, num_heads=opt.dit_num_heads, num_layers=opt.dit_num_layers,
                                  latent_size=opt.point_latent_size, latent_dim=opt.point_latent_dim, clip_dim=CLIP_DIM,
-                                 clip_layers=clip_layers, clip_heads=16, clip_mlp_dim=5120, clip_image_size=224, clip_patch=14,
-                                 weight_dtype=native.ER_F32 if precision == "fp32" else native.ER_F16)
-        self._ctx = C.c_void_p()
+                                 clip_layers=self.clip_layers, clip_heads=16, clip_mlp_dim=5120, clip_image_size=224, clip_patch=14,
+                                 weight_dtype=native.ER_F16 if self._fp16 else native.ER_F32)
+        self._ctx_h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        native.check(self.lib.er_dit_create(C.byref(cfg), idx, C.byref(self._ctx)), "er_dit_create")
-        self.stream = torch.cuda.Stream(device=self.device)
+        native.check(self.lib.er_dit_create(C.byref(cfg), idx, C.byref(self._ctx_h)), "er_dit_create")
+        for sd, strict in self._sources:
+            self._load_now(sd, strict)
+        return self._ctx_h
+
+    @property
+    def _ctx(self):
+        return self._ctx_h if self._ctx_h else self._materialize()
 
     def close(self):
-        if getattr(self, "_ctx", None) is not None and self._ctx:
-            self.lib.er_dit_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        if getattr(self, "_ctx_h", None) is not None and self._ctx_h:
+            self.lib.er_dit_destroy(self._ctx_h)
+            self._ctx_h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -59,30 +84,48 @@ class MDiT:
         except Exception:
             pass
 
-    # nn.Module-shaped conveniences (infer_dit.py:61-71)
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """The dict is kept by reference so that .half() / .float() can rebuild the context in the other precision."""
+        self._sources.append((sd, strict))
+        if self._ctx_h:
+            return self._load_now(sd, strict)
+        return [], []
+
+    def _load_now(self, sd, strict):
         unexpected = []
         for key, t in sd.items():
             t = t.detach().float().contiguous() if t.dtype not in (torch.float32, torch.float16, torch.bfloat16) else t.detach().contiguous()
             dt = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[t.dtype]
             shape = (C.c_int64 * max(1, t.dim()))(*(list(t.shape) or [1]))
-            rc = native.check(self.lib.er_dit_load_tensor(self._ctx, key.encode(), native.ptr(t), dt, max(1, t.dim()), shape,
+            rc = native.check(self.lib.er_dit_load_tensor(self._ctx_h, key.encode(), native.ptr(t), dt, max(1, t.dim()), shape,
                                                           1 if t.is_cuda else 0), f"er_dit_load_tensor({key})")
             if rc == 1:
                 unexpected.append(key)
-        rc = self.lib.er_dit_finalize_weights(self._ctx)
+        rc = self.lib.er_dit_finalize_weights(self._ctx_h)
         missing = [self.lib.er_last_error().decode()] if rc < 0 else []
         if strict and (missing or unexpected):
             raise native.NativeError(f"missing={missing} unexpected={unexpected[:4]}")
         return missing, unexpected
 
-    def half(self):
+    def _cast(self, fp16: bool):
+        if fp16 != self._fp16:
+            self._fp16 = fp16
+            self.close()                   # rebuilt on next use from the retained checkpoints
         return self
+
+    def half(self):
+        """reference infer_dit.py:70: selects the fp16 matrix-core context."""
+        return self._cast(True)
+
+    def float(self):
+        return self._cast(False)
 
     def eval(self):
         return self
 
     def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise native.NativeError("MDiT only runs on a HIP device")
         return self
 
     def _sync_in(self):

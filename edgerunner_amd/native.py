@@ -27,7 +27,7 @@ EXPORTS = [
     "er_kv_reserve", "er_encode_cond", "er_embed_tokens", "er_prefill", "er_logits", "er_feed", "er_decode",
     "er_meto_decode", "er_meto_encode", "er_dit_create", "er_dit_destroy", "er_dit_load_tensor",
     "er_dit_finalize_weights", "er_dit_project_cond", "er_dit_encode_image", "er_dit_forward", "er_dit_sample",
-    "er_kernel_kind_name", "er_profile_decode_kernels", "er_last_decode_ms",
+    "er_kernel_kind_name", "er_profile_decode_kernels", "er_profile_decode_kernels_at", "er_last_decode_ms",
     "er_k_gemv", "er_k_attn_decode", "er_k_gemm", "er_k_gemm_f16", "er_k_flash_attn_f16", "er_k_layernorm", "er_k_softmax", "er_k_sample_head",
 ]
 
@@ -85,6 +85,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.er_feed.argtypes = [vp, C.POINTER(C.c_int32), vp]
     lib.er_decode.argtypes = [vp, C.POINTER(ErDecodeParams), vp, C.POINTER(C.c_int32), vp]
     lib.er_profile_decode_kernels.argtypes = [vp, ci, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]
+    lib.er_profile_decode_kernels_at.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]
     lib.er_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
     i32p = C.POINTER(C.c_int32)
     lib.er_meto_decode.argtypes = [i32p, ci, ci, ci, C.POINTER(C.c_float), i32p, i32p, i32p, i32p, i32p]

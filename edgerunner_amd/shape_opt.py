@@ -63,6 +63,7 @@ class NativeShapeOPT:
         self.stream = torch.cuda.Stream(device=self.device)
         self._reserved = (0, 0)
         self.last_decode_ms = 0.0
+        self.direct_loads = False     # weights loaded on this object directly (LMM.half()/float() cannot replay them)
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -80,6 +81,7 @@ class NativeShapeOPT:
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
         """Same keys as the reference checkpoint.  Returns the
         (missing, unexpected) lists like ``nn.Module.load_state_dict``."""
+        self.direct_loads = True
         unexpected = []
         for key, t in sd.items():
             if not isinstance(t, torch.Tensor):
@@ -89,6 +91,7 @@ class NativeShapeOPT:
 
     def load_state_iter(self, items, strict: bool = False):
         """Streaming variant (one tensor resident at a time)."""
+        self.direct_loads = True
         unexpected = []
         for key, t in items:
             self._load_one(key, t, unexpected)
@@ -209,7 +212,10 @@ class NativeShapeOPT:
 
     def _decode_device(self, B, T, min_new, do_sample, top_k, grammar, seed):
         if seed is None:
-            seed = int(torch.initial_seed()) if do_sample else 0
+            # the reference draws with torch.multinomial on the GLOBAL generator, which advances on every call:
+            # repeated generate() calls give different samples and torch.manual_seed() reproduces a whole script.
+            # Same contract here: the Philox key of this call is itself drawn from torch's global CPU generator.
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0
         p = native.ErDecodeParams(mode=native.ER_SAMPLE if do_sample else native.ER_GREEDY, top_k=int(top_k),
                                   grammar=int(grammar), max_new_tokens=int(T), min_new_tokens=int(min_new),
                                   seed=int(seed) & 0xFFFFFFFFFFFFFFFF)
@@ -256,11 +262,15 @@ class NativeShapeOPT:
         return ids.to(self.device)
 
     # -- measurement -------------------------------------------------------------------------
-    def profile_decode_kernels(self, repeats: int = 5):
+    def profile_decode_kernels(self, repeats: int = 5, context_len: int = 0, use_graph: bool = False):
+        """Per-kind average launch duration (HIP events on the launch stream) and algorithmic bytes per launch.
+        context_len > 0: the attention kernels run over that many keys (default: the current context length);
+        use_graph: the 24 launches of a kind are replayed from a hipGraph, as the generation loop does."""
         us = (C.c_float * native.ER_NUM_KERNEL_KINDS)()
         by = (C.c_double * native.ER_NUM_KERNEL_KINDS)()
         with self._enter():
-            native.check(self.lib.er_profile_decode_kernels(self._ctx, repeats, us, by, self._sp()), "er_profile")
+            native.check(self.lib.er_profile_decode_kernels_at(self._ctx, repeats, int(context_len), 1 if use_graph else 0, us, by,
+                                                               self._sp()), "er_profile")
         self._exit()
         return {self.lib.er_kernel_kind_name(k).decode(): {"avg_us": float(us[k]), "bytes": float(by[k])}
                 for k in range(native.ER_NUM_KERNEL_KINDS)}

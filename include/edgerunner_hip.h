@@ -206,6 +206,12 @@ const char* er_kernel_kind_name(int kind);
  * average duration of ONE launch, bytes_out[kind] = algorithmic HBM bytes of one
  * launch at the current context length.  Does not advance the generation state. */
 int er_profile_decode_kernels(er_ctx* ctx, int repeats, float* avg_us_out, double* bytes_out, void* stream);
+/* Same sweep with the attention kernels run at `context_len` keys (<= the reserved capacity; 0 = the current context
+ * length): lets bench.py time the dominant kernel at the MEAN context length of the run it timed, which is what a
+ * rocprofv3 --stats average over that run reports.  The launches are captured into a hipGraph and replayed, like the
+ * generation loop does (`use_graph` != 0), or issued eagerly. */
+int er_profile_decode_kernels_at(er_ctx* ctx, int repeats, int context_len, int use_graph, float* avg_us_out,
+                                 double* bytes_out, void* stream);
 /* Milliseconds spent inside the last er_decode between its first and last step (HIP events). */
 int er_last_decode_ms(er_ctx* ctx, float* ms_out);
 

@@ -58,22 +58,34 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: this path has no CPU fallback")
     device = torch.device("cuda", local)
-    opt.cond_mode = "point_latent"            # infer_dit.py:55
-    precision = os.environ.get("EDGERUNNER_PRECISION", "fp16")
-    model = LMM(opt, device, precision=precision)
-    model_dit = MDiT(opt, device)
+    torch.cuda.set_device(device)
     from edgerunner_amd import weights as W
+    # The reference builds LMM(opt) with the preset's cond_mode and only then flips it to 'point_latent'
+    # (infer_dit.py:41,55): generate() thereafter skips the point encoder.  The native context is sized by cond_mode, so
+    # the flip happens first here; the checkpoint's point_encoder.* tensors are then simply unexpected keys (strict=False).
+    opt.cond_mode = "point_latent"
+    model = LMM(opt, device, precision=None)          # module style: storage precision follows .half() below
     if opt.resume is not None:
         model.load_state_dict(load_ckpt(opt.resume), strict=False)
+        print(f"[INFO] Loaded checkpoint from {opt.resume}")
     else:
         print("[WARN] model randomly initialized, are you sane?")
-        model.mesh_decoder.load_state_iter(W.iter_state_dict(opt, opt.seed, "reference"), strict=True)
+        model.load_state_dict(W.make_state_dict(opt, opt.seed, "reference"), strict=True)
+    clip_layers = int(os.environ.get("ER_CLIP_LAYERS", "32"))      # test knob: the reference's encoder is ViT-H/14, 32 layers
+    model_dit = MDiT(opt, device, clip_layers=clip_layers, precision=None)
     if opt.resume2 is not None:
         model_dit.load_state_dict(load_ckpt(opt.resume2), strict=False)
+        print(f"[INFO] Loaded checkpoint from {opt.resume2}")
     else:
         sd = W.make_dit_state_dict(opt, opt.seed, "reference")
-        sd.update(W.make_clip_state_dict(32, opt.seed, "reference"))
+        sd.update(W.make_clip_state_dict(clip_layers, opt.seed, "reference"))
         model_dit.load_state_dict(sd, strict=True)
+    # reference infer_dit.py:69-70: both models run fp16 on the GPU; EDGERUNNER_PRECISION=fp32 keeps the exact mode
+    if os.environ.get("EDGERUNNER_PRECISION", "fp16") == "fp32":
+        model, model_dit = model.float().eval().to(device), model_dit.float().eval().to(device)
+    else:
+        model, model_dit = model.half().eval().to(device), model_dit.half().eval().to(device)
+    dit_steps = int(os.environ.get("ER_DIT_STEPS", "100"))         # test knob: MDiT.run's default is 100 (models_dit.py:187)
     tokenizer, _ = get_tokenizer(opt)
 
     assert opt.test_path is not None
@@ -86,7 +98,7 @@ def main(argv=None):
         image = torch.from_numpy(load_image(path)).permute(2, 0, 1).contiguous().unsqueeze(0).float().to(device)
         cond = F.interpolate(image, (512, 512), mode="bilinear", align_corners=False)      # infer_dit.py:97
         t0 = time.time()
-        latents = model_dit.run(cond)
+        latents = model_dit.run(cond, num_inference_steps=dit_steps)
         meshes, tokens = model.generate(latents, num_faces=num_faces, max_new_tokens=opt.test_max_seq_length,
                                         tokenizer=tokenizer, clean=True, seed=opt.seed + 7919 * j)
         tokens = trim_tokens(tokens[0])

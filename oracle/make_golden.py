@@ -9,6 +9,7 @@
 
 Usage:  python oracle/make_golden.py small|eos  # ~1 min each
         python oracle/make_golden.py full       # ~10 min (24 layers, T=4000)
+        python oracle/make_golden.py batch      # ~6 min (24 layers, 3 rows x 3 modes x 48 steps)
 Fixtures are small .npz files; the weights are regenerated from the seed by
 ``edgerunner_amd.weights`` (never committed).
 """
@@ -315,6 +316,61 @@ def make_full(T=4000):
     print("done", ids.shape, f"{t2 - t1:.0f}s; decode tok/s {len(dt) / dt.sum():.2f}")
 
 
+@torch.no_grad()
+def make_batch(T=48):
+    """Per-row goldens for the BATCHED decode kernels (B > 4: matrix-core projections, a different summation order
+    from the single-row path): 24 layers, clouds 0 / 13 / 31 of a 32-cloud batch, per-step logits along
+      (a) the reference modules' own greedy path (fp32, num_faces 1000, EOS suppressed) - BASELINE configs[3] shard;
+      (b) the same in the fp16-storage emulation (weights rounded to fp16, K/V rounded at the cache write);
+      (c) a SAMPLE-mode path (top-k 10, torch generator seeded per row) at num_faces 4000 in the fp16-storage
+          emulation - BASELINE configs[2]'s shape; the top-12 scores after the grammar mask are kept per step.
+    The GPU tests feed these ids (teacher forcing) through a 32-row batch and compare logits / distributions."""
+    opt, ref_opt = opts(24, generate_mode="greedy")
+    t0 = time.time()
+    sd = W.make_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE)
+    model = build_reference(ref_opt, sd)
+    sd16 = O.round_streamed_weights(sd, torch.float16)
+    fwd16 = O.make_forward(sd16, opt, kv_round=torch.float16)
+    rows = [0, 13, 31]
+    out = {"rows": np.array(rows), "T": np.array([T])}
+    ids32, lg32, ids16, lg16, ids_s, top_v, top_i = [], [], [], [], [], [], []
+    for r in rows:
+        pc = W.synthetic_point_cloud(r, 4096)
+        i, l = run_case(model, sd, opt, pc, 1000, T, T, n_logits=T, check_restatement=False)
+        ids32.append(i[0]); lg32.append(l[:, 0])
+        rec = {}
+        i16 = O.lmm_generate_ids(sd16, opt, pc, 1000, max_new_tokens=T, min_new_tokens=T, fwd=fwd16,
+                                 record_logits=lambda t, s_: rec.__setitem__(t, s_.numpy()[0].copy()))
+        ids16.append(i16.numpy()[0]); lg16.append(np.stack([rec[t] for t in range(T)]))
+        # sample mode, face bucket 3: ids from torch.multinomial with a per-row CPU generator; masked scores recorded
+        sopt = dataclasses.replace(opt, generate_mode="sample")
+        rec_s = {}
+        g = torch.Generator().manual_seed(4000 + r)
+        isamp = O.lmm_generate_ids(sd16, sopt, pc, 4000, max_new_tokens=T, min_new_tokens=T, fwd=fwd16, generator=g,
+                                   record_logits=lambda t, s_: rec_s.__setitem__(t, s_.numpy()[0].copy()))
+        isamp = isamp.numpy()[0]
+        ids_s.append(isamp)
+        fn = O.make_allowed_fn(opt, 518, True)
+        tv, ti = [], []
+        for t in range(T):
+            sc = torch.from_numpy(rec_s[t])[None].clone()
+            sc[:, opt.eos_token_id] = -float("inf")                       # min_new_tokens == T
+            sc = O.prefix_constrained_scores(sc, torch.from_numpy(isamp[None, :t]), [fn])
+            v, ix = torch.topk(sc[0], 12)
+            tv.append(v.numpy()); ti.append(ix.numpy())
+        top_v.append(np.stack(tv)); top_i.append(np.stack(ti))
+        print(f"row {r}: {time.time() - t0:.0f}s", flush=True)
+    out.update(ids_fp32=np.stack(ids32), logits_fp32=np.stack(lg32), ids_fp16=np.stack(ids16), logits_fp16=np.stack(lg16),
+               ids_sample=np.stack(ids_s), sample_top_scores=np.stack(top_v), sample_top_ids=np.stack(top_i).astype(np.int32))
+    np.savez_compressed(os.path.join(GOLD, "arae_batch.npz"), **out)
+    manifest_update("arae_batch", {"num_layers": 24, "rows": rows, "T": T,
+                                   "fp32": "reference modules under the restated loop (greedy, num_faces 1000)",
+                                   "fp16": "oracle restatement, fp16-rounded streamed weights + fp16-rounded K/V",
+                                   "sample": "fp16 emulation, num_faces 4000, top_k 10, torch.Generator().manual_seed(4000 + row)",
+                                   "cases": {k: list(v.shape) for k, v in out.items()}})
+    print({k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
@@ -326,5 +382,7 @@ if __name__ == "__main__":
         make_dit()
     elif what == "full":
         make_full(int(sys.argv[2]) if len(sys.argv) > 2 else 4000)
+    elif what == "batch":
+        make_batch()
     else:
         raise SystemExit(__doc__)

@@ -1,0 +1,51 @@
+#!/bin/bash
+# One gpurun call of round 2.  Usage (build container):
+#   gpurun --timeout 1500 -- 'bash scripts/gpu_round2.sh tests tune bench prof pmc probes'
+# Sections run in the order given; every section writes its log under gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/device.txt
+filt() { grep -v amdgpu.ids; }
+for SEC in "$@"; do
+  echo "=================== $SEC"
+  case "$SEC" in
+    kernels)
+      timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider --timeout 300 2>&1 | filt | tail -30 | tee gpurun_out/test_kernels.log ;;
+    parity)
+      timeout 2400 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -p no:cacheprovider --timeout 1200 2>&1 | filt | tail -80 | tee gpurun_out/test_parity.log ;;
+    scripts)
+      timeout 1800 python -m pytest tests/test_gpu_scripts.py -q -m gpu -s -p no:cacheprovider --timeout 1200 2>&1 | filt | tail -60 | tee gpurun_out/test_scripts.log ;;
+    dit)
+      timeout 1800 python -m pytest tests/test_gpu_dit.py -q -m gpu -s -p no:cacheprovider --timeout 1200 2>&1 | filt | tail -40 | tee gpurun_out/test_dit.log ;;
+    alltests)
+      timeout 3000 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 1500 --durations=15 2>&1 | filt | tail -60 | tee gpurun_out/test_all.log ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | filt | tail -5 | tee gpurun_out/smoke.log ;;
+    tune)
+      TUNE_CONFIGS=${TUNE_CONFIGS:-'[{"ER_ATTN_V":1},{"ER_COMBINE_V":1},{"ER_ATTN_V":1,"ER_COMBINE_V":1}]'} \
+        timeout 1200 python scripts/tune_decode.py 2>&1 | filt | tee gpurun_out/tune.log ;;
+    bench)
+      timeout 1200 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 2> gpurun_out/bench.err | tee gpurun_out/bench.json
+      filt < gpurun_out/bench.err | tail -20 ;;
+    bench32)
+      timeout 1200 python bench.py --steps 1 --warmup 1 --batch-per-gpu 32 --precision ${B32_PRECISION:-fp16} --cpu-steps 0 2> gpurun_out/bench32.err | tee gpurun_out/bench32.json
+      filt < gpurun_out/bench32.err | tail -8 ;;
+    prof)
+      rm -rf /tmp/prof
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r02 -- python $ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --no-fast-extra > $ROOT/gpurun_out/rocprof_bench.json 2> $ROOT/gpurun_out/rocprof.err)
+      mkdir -p gpurun_out/prof; find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
+      head -12 gpurun_out/prof/*kernel_stats.csv 2>/dev/null | cut -c1-160; tail -1 gpurun_out/rocprof_bench.json | cut -c1-600
+      python scripts/roofline_from_rocprof.py $(ls gpurun_out/prof/*kernel_stats.csv | head -1) gpurun_out/rocprof_bench.json 2>&1 | tee gpurun_out/roofline_check.log ;;
+    pmc)
+      bash scripts/gpu_pmc.sh 2>&1 | tail -14 ;;
+    probes)
+      for P in ${PROBES:-xcd_barrier_probe persistent_chain_probe}; do
+        if [ -x scripts/probes/$P ]; then echo "--- $P"; timeout 300 scripts/probes/$P 2>&1 | tee gpurun_out/$P.log | tail -40; fi
+      done ;;
+    *) echo "unknown section $SEC" ;;
+  esac
+done
+du -sh gpurun_out
+echo "== done"

@@ -2,7 +2,7 @@
 """Aggregate rocprofv3 CSV output into small JSON summaries that can be committed under profiles/.
 
   pmc_summary.py stats  <kernel_stats.csv>                 -> per-kernel calls / avg us / % (from --kernel-trace --stats)
-  pmc_summary.py pmc    <counter_collection.csv> [...]     -> per-kernel mean counter values per dispatch
+  pmc_summary.py pmc [--attn-context L] <counter_collection.csv> [...]   -> per-kernel mean counter values per dispatch
 
 HBM traffic per launch (MI355X_MICROARCH.md, section HBM): FETCH_SIZE / WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so
@@ -33,7 +33,7 @@ def stats(path):
     print(json.dumps({"source": path, "kernels": out}, indent=1))
 
 
-def pmc(paths):
+def pmc(paths, attn_context=None):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for path in paths:
         for r in csv.DictReader(open(path)):
@@ -49,11 +49,18 @@ def pmc(paths):
         if "WRITE_SIZE" in d:
             d["hbm_write_bytes_per_launch"] = d["WRITE_SIZE"]["mean"] * 1024.0
         out[k] = d
-    print(json.dumps({"sources": paths, "kernels": out}, indent=1))
+    doc = {"sources": paths, "kernels": out}
+    if attn_context is not None:      # mean number of keys the attention launches of this run covered (bench.py scales to its own)
+        doc["attention_context_len_mean"] = attn_context
+    print(json.dumps(doc, indent=1))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     else:
-        pmc(sys.argv[2:])
+        rest = sys.argv[2:]
+        ctx = None
+        if rest and rest[0] == "--attn-context":
+            ctx, rest = float(rest[1]), rest[2:]
+        pmc(rest, ctx)

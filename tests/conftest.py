@@ -56,3 +56,11 @@ def gold_full():
     if not os.path.exists(p):
         pytest.skip("full-size golden not generated")
     return dict(np.load(p))
+
+
+@pytest.fixture(scope="session")
+def gold_batch():
+    p = os.path.join(GOLDEN, "arae_batch.npz")
+    if not os.path.exists(p):
+        pytest.skip("batched-path golden not generated")
+    return dict(np.load(p))

@@ -320,7 +320,11 @@ def test_sample_head_wide_vocabulary_topk():
         nt, _, _ = K.sample_head(logits, 1, 0, step, [7], [0], [1], top_k=3, seed=99)
         u = K.philox_uniform(99, step, 0)
         ref = O.sample_from_uniform(O.top_k_filter(logits.cpu(), 3)[0], u)
-        assert nt[0] in (1025, 1027, 1029) and (nt[0] == ref or abs(nt[0] - ref) <= 4)
+        assert nt[0] in (1025, 1027, 1029)
+        if nt[0] != ref:   # only legal when u sits on a CDF boundary (fp32 summation order), as in the V = 518 test below
+            filt = O.top_k_filter(logits.cpu(), 3)[0]
+            cdf = torch.cumsum(torch.softmax(filt.double(), -1), 0)
+            assert min(abs(float(cdf[nt[0]]) - u), abs(float(cdf[ref]) - u)) < 1e-5, (step, nt, ref, u)
         seen.add(nt[0])
     assert seen == {1025, 1027, 1029}
 

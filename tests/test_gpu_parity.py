@@ -411,6 +411,138 @@ def test_sample_mode_batch_config3_like():
             last = t
 
 
+# ------------------------------------------------------------------ logits THROUGH the batched (B > 4) kernels
+def batched_teacher_forced_logits(lmm, num_faces, ids_by_row, T, B=32, rows_keep=None):
+    """[T, len(rows_keep), V] logits of a B-row batch of DISTINCT clouds (cloud i in row i), every row teacher-forced:
+    the rows in ids_by_row with their own golden ids, the others with the first golden row's ids (rows are independent)."""
+    dec, opt = lmm.mesh_decoder, lmm.opt
+    rows_keep = sorted(ids_by_row) if rows_keep is None else rows_keep
+    default = ids_by_row[sorted(ids_by_row)[0]]
+    batch = torch.cat([cloud(i) for i in range(B)])
+    cond = lmm.encode_cond(batch, [num_faces] * B)["cond_embeds"]
+    emb = torch.cat((cond, dec.embd(torch.full((B, 1), opt.bos_token_id, dtype=torch.long))), dim=1)
+    dec.prefill(emb, T + 2)
+    out = np.zeros((T, len(rows_keep), lmm.vocab_size), np.float32)
+    for t in range(T):
+        out[t] = dec.logits().cpu().numpy()[rows_keep]
+        if t < T - 1:
+            dec.feed([int(ids_by_row.get(r, default)[t]) for r in range(B)])
+    return out
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_batched_kernels_teacher_forced_logits_24_layers(gold_batch, precision):
+    """BASELINE configs[3] shard shape (32 distinct clouds, 24 layers): per-step logits of rows 0 / 13 / 31 THROUGH the
+    B > 4 kernels (matrix-core qkv / fc1 / fc2, batched out_proj / lm_head, batched attention) against the reference
+    modules' fp32 logits (<= 1e-3, north_star) resp. the fp16-storage emulation of the oracle; the row arg-max must
+    reproduce the reference's greedy ids at every step."""
+    rows = [int(r) for r in gold_batch["rows"]]
+    T = int(gold_batch["T"][0])
+    lmm = make_lmm(num_layers=24, precision=precision)
+    ids = gold_batch["ids_" + precision]
+    want = gold_batch["logits_" + precision]                      # [rows, T, V]
+    got = batched_teacher_forced_logits(lmm, 1000, {r: ids[i] for i, r in enumerate(rows)}, T)
+    assert lmm.mesh_decoder._reserved[0] == 32
+    err = np.abs(got.transpose(1, 0, 2) - want)
+    print(f"batched {precision}: max|dlogit| per row {err.max(axis=(1, 2))} over {T} steps")
+    assert err.max() < LOGIT_TOL
+    from edgerunner_amd.grammar import GrammarState
+    from edgerunner_amd import native
+    for i, r in enumerate(rows):                                     # greedy choice from the batched logits == reference ids
+        st, last = GrammarState(native.ER_GRAMMAR_LR_ABSCO, 518), None
+        for t in range(T):
+            allowed = [a for a in st.allowed(last) if a != 2]        # EOS suppressed (min_new_tokens = T)
+            s = np.full(518, -np.inf, np.float32)
+            s[allowed] = got[t, i, allowed]
+            assert int(np.argmax(s)) == int(ids[i, t]), (precision, r, t)
+            last = int(ids[i, t])
+    lmm.mesh_decoder.reserve(1, 4096)
+
+
+def test_forced_batched_kernels_at_B1_logits(gold_batch, monkeypatch):
+    """ER_FORCE_BATCHED=1: the B > 4 kernels on a single row, 24 layers, teacher-forced fp32 logits vs the reference."""
+    lmm = make_lmm(num_layers=24)
+    T = int(gold_batch["T"][0])
+    monkeypatch.setenv("ER_FORCE_BATCHED", "1")
+    lmm.mesh_decoder.reserve(1, 4099)                 # re-reserve so the context re-reads the switch
+    try:
+        got = teacher_forced_logits(lmm, cloud(0), 1000, gold_batch["ids_fp32"][0], set(range(T)))
+    finally:
+        monkeypatch.delenv("ER_FORCE_BATCHED")
+        lmm.mesh_decoder.reserve(1, 4098)
+    err = max(float(np.abs(got[t] - gold_batch["logits_fp32"][0, t]).max()) for t in range(T))
+    print(f"forced-batched B=1: max|dlogit| {err:.3e}")
+    assert err < LOGIT_TOL
+
+
+def test_config2_shape_sample_mode_distributions(gold_batch):
+    """BASELINE configs[2] at reduced length: B = 32 distinct clouds, test_num_face = 4000 (bucket 3), sample mode
+    (top-k 10), fp16 weights + KV, 24 layers.  (i) a real device-sampled run is deterministic per seed, rows differ and
+    obey the grammar; (ii) along the oracle's own sampled path (torch.multinomial on the fp16-storage emulation) the
+    per-step top-10 candidate SET and its softmax probabilities computed from the batched kernels' logits match the
+    oracle's for rows 0 / 13 / 31; (iii) the device sampler's draw at every step equals the inverse-CDF draw from the
+    oracle's distribution with the same Philox uniform."""
+    import arae_oracle as O
+    from edgerunner_amd import kernels as K
+    from edgerunner_amd.grammar import GrammarState
+    from edgerunner_amd import native
+    rows = [int(r) for r in gold_batch["rows"]]
+    T = int(gold_batch["T"][0])
+    lmm = make_lmm(num_layers=24, precision="fp16")
+    batch = torch.cat([cloud(i) for i in range(32)])
+    lmm.opt.generate_mode = "sample"
+    try:
+        a = lmm.generate_ids(batch, 4000, tokenizer=object(), max_new_tokens=T, min_new_tokens=T, seed=21)
+        b = lmm.generate_ids(batch, 4000, tokenizer=object(), max_new_tokens=T, min_new_tokens=T, seed=21)
+    finally:
+        lmm.opt.generate_mode = "greedy"
+    assert torch.equal(a, b)
+    arr = a.cpu().numpy()
+    assert len({tuple(r) for r in arr}) > 16
+    for r in arr[::7]:
+        st, last = GrammarState(native.ER_GRAMMAR_LR_ABSCO, 518), None
+        for t in r.tolist():
+            assert t in st.allowed(last) and t != 2
+            last = t
+    ids = gold_batch["ids_sample"]
+    got = batched_teacher_forced_logits(lmm, 4000, {r: ids[i] for i, r in enumerate(rows)}, T)
+    worst_p, swaps, draws = 0.0, 0, 0
+    for i, r in enumerate(rows):
+        st, last = GrammarState(native.ER_GRAMMAR_LR_ABSCO, 518), None
+        for t in range(T):
+            cnt_before = st.counter
+            allowed = [x for x in st.allowed(last) if x != 2]          # EOS suppressed: min_new_tokens = T
+            s = torch.full((518,), -math.inf)
+            s[allowed] = torch.from_numpy(got[t, i, allowed])
+            gv, gi = gold_batch["sample_top_scores"][i, t], gold_batch["sample_top_ids"][i, t]
+            k = min(10, len(allowed))
+            mine = torch.topk(s, k)
+            if set(mine.indices.tolist()) != set(gi[:k].tolist()):
+                assert k == 10 and abs(float(gv[9] - gv[10])) < 2e-3, (r, t, mine.indices.tolist(), gi.tolist())
+                swaps += 1
+            else:
+                p_ref = torch.softmax(torch.from_numpy(gv[:k].astype(np.float64)), 0).numpy()
+                order = {int(tok): j for j, tok in enumerate(gi[:k].tolist())}
+                p_mine = torch.softmax(mine.values.double(), 0).numpy()
+                for j, tok in enumerate(mine.indices.tolist()):
+                    worst_p = max(worst_p, abs(p_mine[j] - p_ref[order[tok]]))
+            if t % 4 == 0:      # (iii) the device sampler on THESE logits vs the HF distribution + the same Philox uniform
+                nt, _, _ = K.sample_head(torch.from_numpy(got[t, i][None].copy()).to(DEV), 1, native.ER_GRAMMAR_LR_ABSCO, t,
+                                         [0 if last is None else last], [cnt_before], [1], top_k=10, min_new=T, seed=21)
+                u = K.philox_uniform(21, t, 0)
+                filt = O.top_k_filter(s[None], 10)[0]
+                ref = O.sample_from_uniform(filt, u)
+                if nt[0] != ref:
+                    cdf = torch.cumsum(torch.softmax(filt.double(), -1), 0)
+                    assert min(abs(float(cdf[nt[0]]) - u), abs(float(cdf[ref]) - u)) < 1e-5, (r, t, nt, ref, u)
+                assert filt[nt[0]] > -math.inf
+                draws += 1
+            last = int(ids[i, t])
+    print(f"configs[2]-shaped: worst |dp| over top-10 sets {worst_p:.3e}; near-tie set swaps {swaps}; {draws} device draws checked")
+    assert worst_p < 1e-3
+    lmm.mesh_decoder.reserve(1, 4096)
+
+
 # ------------------------------------------------------------------ BASELINE configs[1]: full size, T = 4000
 def test_full_size_greedy_T4000_bit_exact(gold_full, manifest):
     """ArAE 24 layers, cloud 0 (4096 pts), greedy, test_num_face=1000, 4000 new tokens with EOS
