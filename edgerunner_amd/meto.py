@@ -118,18 +118,157 @@ def detokenize_mesh(tokens, discrete_bins: Optional[int] = None, tokenizer: Opti
     return vertices, faces
 
 
+# ------------------------------------------------------------------------------------------------
+# save_mesh's clean-up (core/provider.py:52-58):
+#     mesh = trimesh.Trimesh(vertices, faces)      # process=True: merge_vertices on construction
+#     mesh.merge_vertices(); mesh.update_faces(mesh.unique_faces()); mesh.fix_normals()
+# trimesh is a third-party dependency that is absent from /root/reference and from this image (requirements.txt:
+# `trimesh`, unpinned), so the three calls are RESTATED here from trimesh's published algorithms (4.x: grouping.py
+# merge_vertices, base.py unique_faces, repair.py fix_winding / fix_inversion) - parity unpinned: there is no executable
+# trimesh to check against; the tests pin the properties the calls guarantee.  What is and is not reproduced:
+#   * merge_vertices: referenced vertices whose coordinates agree after rounding to 8 decimals (tol.merge = 1e-8) become
+#     one vertex, unreferenced vertices are dropped.  trimesh orders the surviving vertices by the sort order of a row
+#     hash; here they are ordered lexicographically - same SET of vertices, same faces up to that relabelling.
+#   * unique_faces: of faces that use the same three vertices (in any order / winding) the first is kept.  Degenerate
+#     faces (a repeated vertex) are KEPT, as trimesh keeps them (only Trimesh(validate=True) drops them).
+#   * fix_normals = fix_winding + fix_inversion: inside every edge-connected component (edges shared by exactly two
+#     faces) faces are flipped until neighbours traverse their shared edge in opposite directions (breadth-first from the
+#     component's first face); then a component (or the whole mesh when it is a single body) whose signed volume
+#     sum(v0 . (v1 x v2)) / 6 is negative is inverted.
+def merge_vertices(vertices: np.ndarray, faces: np.ndarray, digits: int = 8):
+    vertices = np.asarray(vertices, dtype=np.float64)
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    if len(vertices) == 0 or len(faces) == 0:
+        return vertices[:0], faces
+    referenced = np.zeros(len(vertices), dtype=bool)
+    referenced[faces.reshape(-1)] = True
+    keys = np.round(vertices * (10.0 ** digits)).astype(np.int64)
+    ref_idx = np.nonzero(referenced)[0]
+    _, first, inv = np.unique(keys[ref_idx], axis=0, return_index=True, return_inverse=True)
+    inverse = np.zeros(len(vertices), dtype=np.int64)
+    inverse[ref_idx] = inv.reshape(-1)
+    return vertices[ref_idx[first]], inverse[faces]
+
+
+def unique_faces_mask(faces: np.ndarray) -> np.ndarray:
+    """Boolean mask of the first occurrence of every vertex triple (order / winding ignored)."""
+    faces = np.asarray(faces).reshape(-1, 3)
+    mask = np.zeros(len(faces), dtype=bool)
+    if len(faces):
+        _, first = np.unique(np.sort(faces, axis=1), axis=0, return_index=True)
+        mask[first] = True
+    return mask
+
+
+def face_adjacency(faces: np.ndarray):
+    """Pairs of distinct faces sharing an edge that exactly two faces use (trimesh graph.face_adjacency) and that edge's
+    two vertex ids."""
+    faces = np.asarray(faces).reshape(-1, 3)
+    if len(faces) == 0:
+        return np.zeros((0, 2), np.int64), np.zeros((0, 2), np.int64)
+    edges = faces[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2)
+    owner = np.repeat(np.arange(len(faces)), 3)
+    key = np.sort(edges, axis=1)
+    order = np.lexsort((key[:, 1], key[:, 0]))
+    ks = key[order]
+    new = np.ones(len(ks), dtype=bool)
+    new[1:] = (ks[1:] != ks[:-1]).any(axis=1)
+    start = np.nonzero(new)[0]
+    count = np.diff(np.append(start, len(ks)))
+    first = start[count == 2]
+    fa = np.stack([owner[order[first]], owner[order[first + 1]]], axis=1)
+    ev = ks[first]
+    keep = fa[:, 0] != fa[:, 1]                                  # a degenerate face can pair an edge with itself
+    return fa[keep], ev[keep]
+
+
+def _traverses(face, u, v) -> bool:
+    """True when `face` walks the edge as u -> v (v is the cyclic successor of u)."""
+    for k in range(3):
+        if face[k] == u and face[(k + 1) % 3] == v:
+            return True
+    return False
+
+
+def fix_normals(vertices: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """trimesh.repair.fix_normals as Trimesh.fix_normals calls it (multibody = body_count > 1): fix_winding - inside
+    every component of the face-adjacency graph, breadth-first from its first face, a face that walks the shared edge in
+    the SAME direction as its already-visited neighbour is reversed - then fix_inversion - a component (or, for a single
+    body, the whole mesh) with negative signed volume is inverted.  Returns the re-wound faces."""
+    faces = np.array(faces, dtype=np.int64).reshape(-1, 3)
+    nf = len(faces)
+    if nf == 0:
+        return faces
+    adj, ev = face_adjacency(faces)
+    nbrs = [[] for _ in range(nf)]
+    for (f0, f1), (u, v) in zip(adj.tolist(), ev.tolist()):
+        nbrs[f0].append((f1, u, v))
+        nbrs[f1].append((f0, u, v))
+    comp = np.full(nf, -1, dtype=np.int64)
+    n_comp = 0
+    for seed in range(nf):
+        if comp[seed] >= 0 or not nbrs[seed]:
+            continue                                             # faces without a manifold edge are not graph nodes: untouched
+        comp[seed] = n_comp
+        queue = [seed]
+        while queue:
+            nxt = []
+            for f in queue:
+                for g, u, v in nbrs[f]:
+                    if comp[g] >= 0:
+                        continue
+                    if _traverses(faces[f], u, v) == _traverses(faces[g], u, v):
+                        faces[g] = faces[g, ::-1]
+                    comp[g] = n_comp
+                    nxt.append(g)
+            queue = nxt
+        n_comp += 1
+    v64 = np.asarray(vertices, dtype=np.float64)
+
+    def volume(mask=None):
+        tri = v64[faces if mask is None else faces[mask]]
+        return float(np.einsum("ij,ij->", tri[:, 0], np.cross(tri[:, 1], tri[:, 2])) / 6.0)
+
+    multibody = _vertex_body_count(len(v64), faces) > 1
+    if not multibody or n_comp <= 1:
+        if volume() < 0.0:
+            faces = faces[:, ::-1].copy()
+        return faces
+    for c in range(n_comp):
+        m = comp == c
+        if volume(m) < 0.0:
+            faces[m] = faces[m][:, ::-1]
+    return faces
+
+
+def _vertex_body_count(nv: int, faces: np.ndarray) -> int:
+    parent = np.arange(nv)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+    for a, b, c in np.asarray(faces).reshape(-1, 3).tolist():
+        ra, rb, rc = find(a), find(b), find(c)
+        parent[rb] = ra
+        parent[rc] = ra
+    used = np.unique(np.asarray(faces).reshape(-1))
+    return len({find(int(i)) for i in used}) if len(used) else 0
+
+
+def clean_like_trimesh(vertices: np.ndarray, faces: np.ndarray):
+    """The whole clean=True branch of save_mesh (see the comment block above)."""
+    v, f = merge_vertices(vertices, faces)
+    f = f[unique_faces_mask(f)]
+    f = fix_normals(v, f)
+    return v, f
+
+
 def merge_and_dedupe(vertices: np.ndarray, faces: np.ndarray):
-    """The index-level part of save_mesh's clean-up (core/provider.py:55-58): merge identical
-    vertices, drop duplicate and degenerate faces.  (trimesh's ``fix_normals`` winding repair is
-    not reproduced.)"""
-    if len(vertices) == 0:
-        return vertices, faces
-    uniq, inv = np.unique(np.round(vertices, 8), axis=0, return_inverse=True)
-    faces = inv.reshape(-1)[faces]
-    keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
-    faces = faces[keep]
-    _, first = np.unique(np.sort(faces, axis=1), axis=0, return_index=True)
-    return uniq, faces[np.sort(first)]
+    """Index-level part only (merge + unique faces); kept for callers that do not want the winding repair."""
+    v, f = merge_vertices(vertices, faces)
+    return v, f[unique_faces_mask(f)]
 
 
 def save_mesh(tokens, opt, path=None, tokenizer=None, clean=True, verbose=False):
@@ -142,7 +281,7 @@ def save_mesh(tokens, opt, path=None, tokenizer=None, clean=True, verbose=False)
     if verbose:
         print(f"[INFO] vertices: {vertices.shape[0]}, faces: {faces.shape[0]}")
     if clean:
-        vertices, faces = merge_and_dedupe(vertices, faces)
+        vertices, faces = clean_like_trimesh(vertices, faces)
         if verbose:
             print(f"[INFO] cleaned vertices: {vertices.shape[0]}, faces: {faces.shape[0]}")
     if path is not None:

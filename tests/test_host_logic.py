@@ -150,3 +150,78 @@ def test_philox_host_replica_known_answers():
     assert philox_uniform(0, 0, 0) == (0x6627e8d5 >> 8) / 2 ** 24
     us = [philox_uniform(1234, t, b) for t in range(200) for b in range(4)]
     assert 0.0 <= min(us) and max(us) < 1.0 and 0.4 < sum(us) / len(us) < 0.6 and len(set(us)) == len(us)
+
+
+# ------------------------------------------------------------------ save_mesh(clean=True): restated trimesh clean-up
+def _cube():
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], dtype=np.float64)
+    # outward-facing winding (positive signed volume)
+    f = np.array([[0, 2, 1], [0, 3, 2], [0, 5, 4], [0, 1, 5], [1, 6, 5], [1, 2, 6], [2, 7, 6], [2, 3, 7], [3, 4, 7], [3, 0, 4],
+                  [4, 6, 7], [4, 5, 6]], dtype=np.int64)
+    return v, f
+
+
+def _signed_volume(v, f):
+    t = v[f]
+    return float(np.einsum("ij,ij->", t[:, 0], np.cross(t[:, 1], t[:, 2])) / 6.0)
+
+
+def _winding_consistent(f):
+    from edgerunner_amd import meto
+    adj, ev = meto.face_adjacency(f)
+    return all(meto._traverses(f[a], u, w) != meto._traverses(f[b], u, w) for (a, b), (u, w) in zip(adj.tolist(), ev.tolist()))
+
+
+def test_clean_like_trimesh_merge_unique_and_winding():
+    """core/provider.py:52-58 semantics (trimesh restated, see edgerunner_amd/meto.py): triangle soup -> shared vertices,
+    duplicate faces dropped (any winding), DEGENERATE faces kept, winding made consistent, volume made positive."""
+    from edgerunner_amd import meto
+    v, f = _cube()
+    assert _signed_volume(v, f) == pytest.approx(1.0)
+    rng = np.random.default_rng(0)
+    # soup: every face gets private copies of its vertices (jittered below the 1e-8 merge tolerance), 5 faces flipped,
+    # one face duplicated with the other winding, one degenerate face, one unreferenced vertex
+    flip = [1, 4, 5, 8, 11]
+    soup_f = f.copy()
+    soup_f[flip] = soup_f[flip][:, ::-1]
+    sv = v[soup_f].reshape(-1, 3) + rng.uniform(-2e-9, 2e-9, size=(36, 3))
+    sf = np.arange(36).reshape(12, 3)
+    sv = np.vstack([sv, sv[[0]], sv[[2]], sv[[1]], [[5.0, 5.0, 5.0]], sv[[3]], sv[[3]], sv[[4]]])
+    sf = np.vstack([sf, [[36, 37, 38]], [[40, 41, 42]]])       # duplicate of face 0 (reversed) ; degenerate (two copies of one point)
+    cv, cf = meto.clean_like_trimesh(sv, sf)
+    assert len(cv) == 8                                           # merged; the unreferenced vertex is gone
+    assert len(cf) == 13                                          # 12 cube faces + the degenerate one; the duplicate is gone
+    degenerate = [i for i, t in enumerate(cf.tolist()) if len(set(t)) < 3]
+    assert len(degenerate) == 1
+    solid = np.delete(cf, degenerate, axis=0)
+    assert _winding_consistent(solid)
+    assert _signed_volume(cv, solid) == pytest.approx(1.0, abs=1e-6)
+    # a fully inverted cube comes back outward; an already clean mesh is left alone
+    iv, if_ = meto.clean_like_trimesh(v, f[:, ::-1])
+    assert _signed_volume(iv, if_) == pytest.approx(1.0)
+    kv, kf = meto.clean_like_trimesh(v, f)
+    assert np.array_equal(kv, v[np.lexsort((v[:, 2], v[:, 1], v[:, 0]))]) and _signed_volume(kv, kf) == pytest.approx(1.0)
+
+
+def test_clean_like_trimesh_multibody_and_reference_fixtures():
+    from edgerunner_amd import meto
+    v, f = _cube()
+    # two bodies, the second one inside-out with one extra inconsistent face: each body is repaired on its own
+    f2 = f[:, ::-1].copy()
+    f2[3] = f2[3][::-1]
+    vv = np.vstack([v, v + 3.0])
+    ff = np.vstack([f, f2 + 8])
+    cv, cf = meto.clean_like_trimesh(vv, ff)
+    assert len(cv) == 16 and len(cf) == 24 and _winding_consistent(cf)
+    lo = cf[(cv[cf][:, :, 0] < 2).all(axis=1)]
+    hi = cf[(cv[cf][:, :, 0] > 2).all(axis=1)]
+    assert _signed_volume(cv, lo) == pytest.approx(1.0) and _signed_volume(cv, hi) == pytest.approx(1.0)
+    # reference fixture 'lRlre' (meto/tests/engine.py:66-71): a strip whose second triangle is flipped -> consistent after the clean-up
+    sv = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [-1, 1, 0], [-1, 2, 0], [-2, 2, 0]], dtype=np.float64)
+    sfaces = np.array([[0, 1, 2], [0, 3, 2], [0, 3, 4], [4, 3, 5], [5, 4, 6]])
+    assert not _winding_consistent(sfaces)
+    _, cfaces = meto.clean_like_trimesh(sv, sfaces)
+    assert len(cfaces) == 5 and _winding_consistent(cfaces)
+    # empty input
+    ev, ef = meto.clean_like_trimesh(np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64))
+    assert len(ev) == 0 and len(ef) == 0
