@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,7 @@
 #include "k_head.h"
 #include "k_rowops.h"
 #include "k_flash_attn.h"
+#include "k_flash_attn_f32.h"
 #include "meto_decode.h"
 #include "meto_encode.h"
 
@@ -109,7 +111,9 @@ struct er_ctx {
     bool batched_valu = false;   // ER_BATCHED_VALU=1: the older VALU kernels (one pass per 16 rows), kept for A/B runs
     float* skpart = nullptr;  // split-K partials of the batched fc2
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
-    int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
+    int rw_qkv = 2, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
+    int nw_qkv = 3, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV / ER_NW_OUT: 3 or 4)
+    bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -210,12 +214,15 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     const char* ng = getenv("ER_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
-    c->rw_qkv = env_int("ER_RW_QKV", 1);
+    c->rw_qkv = env_int("ER_RW_QKV", 2);
+    c->nw_qkv = env_int("ER_NW_QKV", 3) == 4 ? 4 : 3;
+    c->nw_out = env_int("ER_NW_OUT", 3) == 4 ? 4 : 3;
     c->rw_fc1 = env_int("ER_RW_FC1", 2);
     c->rw_fc2 = env_int("ER_RW_FC2", 2);
     c->rw_out = env_int("ER_RW_OUT", 1);
     c->attn_steps = env_int("ER_ATTN_STEPS", ATTN_STEPS_DEFAULT);
     if (c->attn_steps != 2 && c->attn_steps != 8) c->attn_steps = 4;
+    c->flash_prefill = env_int("ER_PREFILL_ATTN", 2) != 1;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
@@ -520,7 +527,7 @@ struct StepPlan {   // which kinds to launch (profiling launches one kind at a t
     int only_layer = -1;
 };
 
-template <typename WT, int KS, int RW, int PRO, int EPI>
+template <typename WT, int KS, int RW, int PRO, int EPI, int NW = ER_NWAVES>
 static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
     // rows are processed in groups of 4/2/1 (K = 6144 keeps <= 2 rows of input in LDS)
     const int maxnb = (KS == 1) ? 4 : 2;
@@ -541,25 +548,28 @@ static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
         if (g.kcache) g.kcache = (char*)g.kcache + kvb;
         if (g.vcache) g.vcache = (char*)g.vcache + kvb;
         hipError_t e;
-        if (nb == 4) e = launch_gemv<WT, KS, (KS == 1 ? 4 : 2), RW, PRO, EPI>(g, st);
-        else if (nb == 2) e = launch_gemv<WT, KS, 2, RW, PRO, EPI>(g, st);
-        else e = launch_gemv<WT, KS, 1, RW, PRO, EPI>(g, st);
+        if (nb == 4) e = launch_gemv<WT, KS, (KS == 1 ? 4 : 2), RW, PRO, EPI, NW>(g, st);
+        else if (nb == 2) e = launch_gemv<WT, KS, 2, RW, PRO, EPI, NW>(g, st);
+        else e = launch_gemv<WT, KS, 1, RW, PRO, EPI, NW>(g, st);
         if (e != hipSuccess) return e;
         b += nb;
     }
     return hipSuccess;
 }
 
+// rows per wave (rw = 1 / 2 / 4) and waves per workgroup (nw = 3 / 4; 3-wave workgroups exist with rw <= 2 only)
 template <typename WT, int KS, int PRO, int EPI>
-static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st) {
-    if constexpr (sizeof(WT) == 2) {     // fp16 rows are half as long: twice the rows per wave keeps the bytes in flight
-        return rw >= 2 ? gemv_groups<WT, KS, 4, PRO, EPI>(a, B, K, st) : gemv_groups<WT, KS, 2, PRO, EPI>(a, B, K, st);
-    } else {
-        switch (rw) {
-            case 1: return gemv_groups<WT, KS, 1, PRO, EPI>(a, B, K, st);
-            case 4: return gemv_groups<WT, KS, 4, PRO, EPI>(a, B, K, st);
-            default: return gemv_groups<WT, KS, 2, PRO, EPI>(a, B, K, st);
+static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st, int nw = ER_NWAVES) {
+    if constexpr (KS == 1) {
+        if (nw == 3) {
+            if (rw == 1) return gemv_groups<WT, KS, 1, PRO, EPI, 3>(a, B, K, st);
+            return gemv_groups<WT, KS, 2, PRO, EPI, 3>(a, B, K, st);
         }
+    }
+    switch (rw) {
+        case 1: return gemv_groups<WT, KS, 1, PRO, EPI>(a, B, K, st);
+        case 4: return gemv_groups<WT, KS, 4, PRO, EPI>(a, B, K, st);
+        default: return gemv_groups<WT, KS, 2, PRO, EPI>(a, B, K, st);
     }
 }
 
@@ -664,8 +674,8 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 if (!c->batched_valu) { a.W = L.wqkv_t; return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, c->skpart, st); }   // 144 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_QKV>(a, B, H, st);   // 4608 rows = 192 workgroups x 24: one round
             }
-            if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st);
-            return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st);
+            if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
+            return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
         }
         case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st, c->attn_v);
         case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
@@ -674,7 +684,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
             // (48 row tiles would leave the matrix-core kernel on 48 CUs: the narrow out_proj stays on the VALU kernel)
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
-            return gemv_rw<WT, 1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st);
+            return gemv_rw<WT, 1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st, c->nw_out);
         }
         case 4: {   // h1 = LN1(ypre1); f = relu(fc1 h1 + b)
             const LayerW& L = c->layers[layer];
@@ -793,65 +803,89 @@ extern "C" int er_encode_cond(er_ctx* c, const float* conds, int B, int n_points
     if (g.cond_mode != ER_COND_NONE && !conds) return fail(ER_ERR_INVALID, "er_encode_cond: conds is null");
     if (LD % 16) return fail(ER_ERR_UNSUPPORTED, "point_latent_dim must be a multiple of 16");
 
-    for (int b = 0; b < B; ++b) {
-        const float* lat = nullptr;   // [Lq][LD]
+    const int PHh = g.point_num_heads > 0 ? g.point_num_heads : 1, PD = PH / PHh;
+    // samples are encoded in chunks of up to 32 (scratch for one chunk at N = 4096: ~5 GB); every GEMM / LayerNorm /
+    // attention launch of a chunk covers all of its samples
+    constexpr int ENC_CHUNK = 32;
+    for (int b0 = 0; b0 < B; b0 += ENC_CHUNK) {
+        const int nb = std::min(ENC_CHUNK, B - b0);
+        const float* lat = nullptr;   // [nb][Lq][LD]
         if (g.cond_mode == ER_COND_POINT) {
             const int N = n_points;
             if (N <= 0) return fail(ER_ERR_INVALID, "n_points must be > 0");
-            const int PHh = g.point_num_heads, PD = PH / PHh;
-            const int ldS = (N + 15) / 16 * 16;
-            ERCHK(ensure(c->e_a0, (size_t)N * c->pe_kpad));
-            ERCHK(ensure(c->e_x, (size_t)N * PH));
-            ERCHK(ensure(c->e_k, (size_t)N * PH));
-            ERCHK(ensure(c->e_v, (size_t)N * PH));
+            const size_t R = (size_t)nb * N, RQ = (size_t)nb * Lq;
+            ERCHK(ensure(c->e_a0, R * c->pe_kpad));
+            ERCHK(ensure(c->e_x, R * PH));
+            ERCHK(ensure(c->e_k, R * PH));
+            ERCHK(ensure(c->e_v, R * PH));
             ERCHK(ensure(c->e_qln, (size_t)Lq * PH));
             ERCHK(ensure(c->e_q, (size_t)Lq * PH));
-            ERCHK(ensure(c->e_sc, (size_t)PHh * Lq * ldS));
-            ERCHK(ensure(c->e_att, (size_t)Lq * PH));
-            ERCHK(ensure(c->e_l, (size_t)Lq * PH));
-            ERCHK(ensure(c->e_ln, (size_t)Lq * PH));
-            ERCHK(ensure(c->e_u, (size_t)Lq * 8 * PH));
-            ERCHK(ensure(c->e_g, (size_t)Lq * 4 * PH));
-            ERCHK(ensure(c->e_lat, (size_t)Lq * LD));
-            const float* pts = conds + (size_t)b * N * 3;
+            ERCHK(ensure(c->e_att, RQ * PH));
+            ERCHK(ensure(c->e_l, RQ * PH));
+            ERCHK(ensure(c->e_ln, RQ * PH));
+            ERCHK(ensure(c->e_u, RQ * 8 * PH));
+            ERCHK(ensure(c->e_g, RQ * 4 * PH));
+            ERCHK(ensure(c->e_lat, RQ * LD));
+            const float* pts = conds + (size_t)b0 * N * 3;
             // x = ln(point_embed(pts))                                          point.py:194
-            hipLaunchKernelGGL(point_embed_kernel, dim3(ew_grid((long long)N * c->pe_kpad)), dim3(ER_WG), 0, st, pts,
-                               c->pe_basis, c->e_a0.p, (long long)N, g.point_freq_dim, c->pe_kpad);
+            hipLaunchKernelGGL(point_embed_kernel, dim3(ew_grid((long long)R * c->pe_kpad)), dim3(ER_WG), 0, st, pts,
+                               c->pe_basis, c->e_a0.p, (long long)R, g.point_freq_dim, c->pe_kpad);
             HIPRET(hipGetLastError());
-            HIPRET(linear(c->e_a0.p, c->pe_kpad, c->pe_mlp_w, c->pe_mlp_b, c->e_x.p, PH, N, PH, c->pe_kpad, false, nullptr, 0, st));
-            HIPRET(launch_layernorm(c->e_x.p, c->pe_ln_w, c->pe_ln_b, c->e_x.p, N, PH, PH, PH, g.ln_eps, st));
+            HIPRET(linear(c->e_a0.p, c->pe_kpad, c->pe_mlp_w, c->pe_mlp_b, c->e_x.p, PH, (int)R, PH, c->pe_kpad, false, nullptr, 0, st));
+            HIPRET(launch_layernorm(c->e_x.p, c->pe_ln_w, c->pe_ln_b, c->e_x.p, (int)R, PH, PH, PH, g.ln_eps, st));
             // cross attention: l = q + out_proj(attn(q_proj(ln1(q)), k_proj(x), v_proj(x)))   point.py:123-124
+            // (the learned queries and their projection are the same for every sample: computed once)
             HIPRET(launch_layernorm(c->pe_query, c->ca_ln1_w, c->ca_ln1_b, c->e_qln.p, Lq, PH, PH, PH, g.ln_eps, st));
             HIPRET(linear(c->e_qln.p, PH, c->ca_q_w, c->ca_q_b, c->e_q.p, PH, Lq, PH, PH, false, nullptr, 0, st));
-            HIPRET(linear(c->e_x.p, PH, c->ca_k_w, c->ca_k_b, c->e_k.p, PH, N, PH, PH, false, nullptr, 0, st));
-            HIPRET(linear(c->e_x.p, PH, c->ca_v_w, c->ca_v_b, c->e_v.p, PH, N, PH, PH, false, nullptr, 0, st));
-            ERCHK(attention_full(c->e_q.p, PH, c->e_k.p, PH, PD, c->e_v.p, PH, PD, c->e_att.p, PH, c->e_sc.p, PHh, PD, Lq, N,
-                                 false, st));
-            HIPRET(linear(c->e_att.p, PH, c->ca_o_w, c->ca_o_b, c->e_l.p, PH, Lq, PH, PH, false, c->pe_query, PH, st));
+            HIPRET(linear(c->e_x.p, PH, c->ca_k_w, c->ca_k_b, c->e_k.p, PH, (int)R, PH, PH, false, nullptr, 0, st));
+            HIPRET(linear(c->e_x.p, PH, c->ca_v_w, c->ca_v_b, c->e_v.p, PH, (int)R, PH, PH, false, nullptr, 0, st));
+            if (c->flash_prefill && (PD == 64 || PD == 96)) {
+                Flash32Args f{};
+                f.Q = c->e_q.p; f.ldq = PH; f.qs_b = 0; f.qs_h = PD;                      // queries shared by the batch
+                f.K = c->e_k.p; f.ldk = PH; f.ks_b = (long long)N * PH; f.ks_h = PD;
+                f.V = c->e_v.p; f.ldv = PH; f.vs_b = (long long)N * PH; f.vs_h = PD;
+                f.O = c->e_att.p; f.ldo = PH; f.os_b = (long long)Lq * PH; f.os_h = PD;
+                f.N = Lq; f.M = N; f.sqrt_d = sqrtf((float)PD); f.causal_off = 0;
+                HIPRET(launch_flash_attn_f32(f, PD, false, PHh, nb, st));
+            } else {
+                const int ldS = (N + 15) / 16 * 16;
+                ERCHK(ensure(c->e_sc, (size_t)PHh * Lq * ldS));
+                for (int b = 0; b < nb; ++b)
+                    ERCHK(attention_full(c->e_q.p, PH, c->e_k.p + (size_t)b * N * PH, PH, PD, c->e_v.p + (size_t)b * N * PH, PH, PD,
+                                         c->e_att.p + (size_t)b * Lq * PH, PH, c->e_sc.p, PHh, PD, Lq, N, false, st));
+            }
+            {   // l = query_embed + out_proj(att): the residual table has Lq rows shared by every sample
+                GemmArgs ga = gemm_args_default();
+                ga.A = c->e_att.p; ga.B = c->ca_o_w; ga.C = c->e_l.p; ga.bias = c->ca_o_b; ga.resid = c->pe_query; ga.resid_mod = Lq;
+                ga.M = (int)RQ; ga.N = PH; ga.K = PH; ga.lda = PH; ga.ldb = PH; ga.ldc = PH; ga.ldr = PH;
+                HIPRET(launch_gemm(ga, 1, st));
+            }
             // l = l + net2(GEGLU(net0(ln2(l))))                                   point.py:125, 68-84
-            HIPRET(launch_layernorm(c->e_l.p, c->ca_ln2_w, c->ca_ln2_b, c->e_ln.p, Lq, PH, PH, PH, g.ln_eps, st));
-            HIPRET(linear(c->e_ln.p, PH, c->ff0_w, c->ff0_b, c->e_u.p, 8 * PH, Lq, 8 * PH, PH, false, nullptr, 0, st));
-            hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)Lq * 4 * PH)), dim3(ER_WG), 0, st, c->e_u.p, c->e_g.p,
-                               (long long)Lq, 4 * PH);
+            HIPRET(launch_layernorm(c->e_l.p, c->ca_ln2_w, c->ca_ln2_b, c->e_ln.p, (int)RQ, PH, PH, PH, g.ln_eps, st));
+            HIPRET(linear(c->e_ln.p, PH, c->ff0_w, c->ff0_b, c->e_u.p, 8 * PH, (int)RQ, 8 * PH, PH, false, nullptr, 0, st));
+            hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)RQ * 4 * PH)), dim3(ER_WG), 0, st, c->e_u.p, c->e_g.p,
+                               (long long)RQ, 4 * PH);
             HIPRET(hipGetLastError());
-            HIPRET(linear(c->e_g.p, 4 * PH, c->ff2_w, c->ff2_b, c->e_l.p, PH, Lq, PH, 4 * PH, false, c->e_l.p, PH, st));
+            HIPRET(linear(c->e_g.p, 4 * PH, c->ff2_w, c->ff2_b, c->e_l.p, PH, (int)RQ, PH, 4 * PH, false, c->e_l.p, PH, st));
             // latent mean = linear(l)                                              point.py:201
-            HIPRET(linear(c->e_l.p, PH, c->lin_w, c->lin_b, c->e_lat.p, LD, Lq, LD, PH, false, nullptr, 0, st));
+            HIPRET(linear(c->e_l.p, PH, c->lin_w, c->lin_b, c->e_lat.p, LD, (int)RQ, LD, PH, false, nullptr, 0, st));
             lat = c->e_lat.p;
         } else if (g.cond_mode == ER_COND_POINT_LATENT) {
-            lat = conds + (size_t)b * Lq * LD;
+            lat = conds + (size_t)b0 * Lq * LD;
         }
-        float* out_b = cond_out + (size_t)b * C * H;
         if (lat) {   // norm_cond(proj_cond(latent))                               core/models.py:124 / 128-129
-            ERCHK(ensure(c->e_tmp, (size_t)Lq * H));
-            HIPRET(linear(lat, LD, c->proj_w, c->proj_b, c->e_tmp.p, H, Lq, H, LD, false, nullptr, 0, st));
-            HIPRET(launch_layernorm(c->e_tmp.p, c->normc_w, c->normc_b, out_b, Lq, H, H, H, g.ln_eps, st));
+            ERCHK(ensure(c->e_tmp, (size_t)nb * Lq * H));
+            HIPRET(linear(lat, LD, c->proj_w, c->proj_b, c->e_tmp.p, H, nb * Lq, H, LD, false, nullptr, 0, st));
         }
-        if (n_face) {   // embed_num_face(quantize_num_faces(n))                     core/models.py:135-139
-            const int bucket = face_bucket ? face_bucket[b] : 0;
-            if (bucket < 0 || bucket >= g.num_face_buckets) return fail(ER_ERR_INVALID, "face bucket %d out of range", bucket);
-            HIPCHK(hipMemcpyAsync(out_b + (size_t)n_lat * H, c->embed_num_face + (size_t)bucket * H, (size_t)H * 4,
-                                  hipMemcpyDeviceToDevice, st));
+        for (int b = 0; b < nb; ++b) {
+            float* out_b = cond_out + (size_t)(b0 + b) * C * H;
+            if (lat) HIPRET(launch_layernorm(c->e_tmp.p + (size_t)b * Lq * H, c->normc_w, c->normc_b, out_b, Lq, H, H, H, g.ln_eps, st));
+            if (n_face) {   // embed_num_face(quantize_num_faces(n))                     core/models.py:135-139
+                const int bucket = face_bucket ? face_bucket[b0 + b] : 0;
+                if (bucket < 0 || bucket >= g.num_face_buckets) return fail(ER_ERR_INVALID, "face bucket %d out of range", bucket);
+                HIPCHK(hipMemcpyAsync(out_b + (size_t)n_lat * H, c->embed_num_face + (size_t)bucket * H, (size_t)H * 4,
+                                      hipMemcpyDeviceToDevice, st));
+            }
         }
     }
     return ER_OK;
@@ -888,7 +922,6 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
     ERCHK(ensure(c->p_a, (size_t)M * H));
     ERCHK(ensure(c->p_y, (size_t)M * H));
     ERCHK(ensure(c->p_f, (size_t)M * I));
-    ERCHK(ensure(c->p_sc, (size_t)NH * S * ldS));
     float *h = c->p_h.p, *q = c->p_q.p, *a = c->p_a.p, *y = c->p_y.p, *f = c->p_f.p;
 
     // hidden = inputs_embeds + pos_embeds(0..S)                       modeling_opt.py:355-357
@@ -906,10 +939,21 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
             qa.q = q; qa.kcache = (float*)kc; qa.vcache = (float*)vc; qa.S = S; qa.hidden = H; qa.head_dim = D; qa.l_cap = c->Lcap;
             qa.kv_bstride = c->kv_bstride;
             HIPRET(launch_gemm(qa, 1, st));
-            for (int b = 0; b < B; ++b)   // causal attention over the prefix     modeling_opt.py:229
-                ERCHK(attention_full(q + (size_t)b * S * H, H, (float*)kc + b * c->kv_bstride, D, (long long)c->Lcap * D,
-                                     (float*)vc + b * c->kv_bstride, D, (long long)c->Lcap * D, a + (size_t)b * S * H, H,
-                                     c->p_sc.p, NH, D, S, S, true, st));
+            if (c->flash_prefill) {       // causal attention over the prefix, all samples and heads in one launch   modeling_opt.py:229
+                Flash32Args f{};
+                f.Q = q; f.ldq = H; f.qs_b = (long long)S * H; f.qs_h = D;
+                f.K = (float*)kc; f.ldk = D; f.ks_b = c->kv_bstride; f.ks_h = (long long)c->Lcap * D;
+                f.V = (float*)vc; f.ldv = D; f.vs_b = c->kv_bstride; f.vs_h = (long long)c->Lcap * D;
+                f.O = a; f.ldo = H; f.os_b = (long long)S * H; f.os_h = D;
+                f.N = S; f.M = S; f.sqrt_d = sqrtf((float)D); f.causal_off = 0;
+                HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
+            } else {
+                ERCHK(ensure(c->p_sc, (size_t)NH * S * ldS));
+                for (int b = 0; b < B; ++b)
+                    ERCHK(attention_full(q + (size_t)b * S * H, H, (float*)kc + b * c->kv_bstride, D, (long long)c->Lcap * D,
+                                         (float*)vc + b * c->kv_bstride, D, (long long)c->Lcap * D, a + (size_t)b * S * H, H,
+                                         c->p_sc.p, NH, D, S, S, true, st));
+            }
         } else {
             // fast mode: fused projection into fp32 scratch [M][3H]; K/V rounded to the cache dtype (fp16) both in
             // the cache and in the scratch the prefix attention reads
@@ -919,10 +963,21 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
             hipLaunchKernelGGL(kv_scatter_half_kernel, dim3(ew_grid((long long)M * 2 * H)), dim3(ER_WG), 0, st, qkv,
                                (_Float16*)kc, (_Float16*)vc, M, S, H, D, c->Lcap, c->kv_bstride);
             HIPRET(hipGetLastError());
-            for (int b = 0; b < B; ++b) {
-                float* base = qkv + (size_t)b * S * 3 * H;
-                ERCHK(attention_full(base, 3 * H, base + H, 3 * H, D, base + 2 * H, 3 * H, D, a + (size_t)b * S * H, H,
-                                     c->p_sc.p, NH, D, S, S, true, st));
+            if (c->flash_prefill) {
+                Flash32Args f{};
+                f.Q = qkv; f.ldq = 3 * H; f.qs_b = (long long)S * 3 * H; f.qs_h = D;
+                f.K = qkv + H; f.ldk = 3 * H; f.ks_b = f.qs_b; f.ks_h = D;
+                f.V = qkv + 2 * H; f.ldv = 3 * H; f.vs_b = f.qs_b; f.vs_h = D;
+                f.O = a; f.ldo = H; f.os_b = (long long)S * H; f.os_h = D;
+                f.N = S; f.M = S; f.sqrt_d = sqrtf((float)D); f.causal_off = 0;
+                HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
+            } else {
+                ERCHK(ensure(c->p_sc, (size_t)NH * S * ldS));
+                for (int b = 0; b < B; ++b) {
+                    float* base = qkv + (size_t)b * S * 3 * H;
+                    ERCHK(attention_full(base, 3 * H, base + H, 3 * H, D, base + 2 * H, 3 * H, D, a + (size_t)b * S * H, H,
+                                         c->p_sc.p, NH, D, S, S, true, st));
+                }
             }
         }
         // y = h + out_proj(a); h1 = LN1(y)                               modeling_opt.py:232, 272-274
@@ -1294,6 +1349,21 @@ extern "C" int er_k_flash_attn_f16(const float* q, const float* k, const float* 
     a.qs_b = (long long)N * H * FA_D; a.os_b = a.qs_b; a.ks_b = (long long)M * H * FA_D; a.vs_b = a.ks_b;
     a.head_stride = FA_D; a.scale = 1.0f / sqrtf((float)FA_D);
     HIPRET(launch_flash_attn_f16(a, H, B, (hipStream_t)stream));
+    return ER_OK;
+}
+
+extern "C" int er_k_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int N, int M, int D,
+                                   int causal, void* stream) {
+    // q/o: [B, N, H*D], k/v: [B, M, H*D] fp32, heads side by side in a row; causal: key j visible to query i iff j <= i + (M - N)
+    if (D != 64 && D != 96) return fail(ER_ERR_UNSUPPORTED, "er_k_flash_attn_f32: head_dim %d (64, 96)", D);
+    if (causal && M < N) return fail(ER_ERR_INVALID, "er_k_flash_attn_f32: causal needs M >= N");
+    Flash32Args a{};
+    a.Q = q; a.K = k; a.V = v; a.O = o; a.N = N; a.M = M;
+    a.ldq = a.ldk = a.ldv = a.ldo = H * D;
+    a.qs_b = (long long)N * H * D; a.os_b = a.qs_b; a.ks_b = (long long)M * H * D; a.vs_b = a.ks_b;
+    a.qs_h = a.ks_h = a.vs_h = a.os_h = D;
+    a.sqrt_d = sqrtf((float)D); a.causal_off = M - N;
+    HIPRET(launch_flash_attn_f32(a, D, causal != 0, H, B, (hipStream_t)stream));
     return ER_OK;
 }
 

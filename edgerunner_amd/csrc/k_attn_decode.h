@@ -353,14 +353,45 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
 }
 
 // attn_combine2_kernel, grid (H, B), 256 threads: one memory round trip.  Thread (c, half) issues ALL of its column loads
-// (partials half, half+2, ... of a pass of up to 64 partials) before anything else; every wave then redundantly loads the
-// pass's {m_s, l_s} with lane = s, so the global max / weights / sum need wave shuffles only (no LDS, no barrier), and the
-// weight of partial s reaches the column accumulation through a wave-uniform readlane.  Longer contexts (> 64 partials,
-// L > 8192) run further passes with the usual running-max rescale.
+// (partials half, half+2, ... of a pass) before anything else; every wave then redundantly loads the pass's {m_s, l_s}
+// with lane = s, so the global max / weights / sum need wave shuffles only (no LDS, no barrier), and the weight of
+// partial s reaches the column accumulation through a wave-uniform readlane.  A pass covers up to 64 partials; its
+// unrolled load count is picked from the number of partials actually left (8 / 16 / 24 / 32 per thread) so that short
+// contexts do not wait for redundant loads.  Longer contexts (> 64 partials, L > 8192) run further passes with the
+// usual running-max rescale.
+template <int D, int PER>
+__device__ __forceinline__ void combine_pass(const float* pb, int base, int n_act, int cc, int half, int lane, float& M_run,
+                                             float& l_run, float& o_run) {
+    constexpr int W = D + 2;
+    float v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int sidx = min(base + half + 2 * u, n_act - 1);   // clamped: loads stay unconditional
+        v[u] = pb[sidx * W + 2 + cc];
+    }
+    const int sl = base + lane;
+    const bool act = sl < n_act && lane < 2 * PER;
+    const float m_s = act ? pb[sl * W] : -INFINITY;
+    const float l_s = act ? pb[sl * W + 1] : 0.f;
+    const float M_new = fmaxf(M_run, wave_max(m_s));
+    const float w = act ? expf(m_s - M_new) : 0.f;
+    const float l_blk = wave_sum(l_s * w);
+    const float alpha = (M_run == -INFINITY) ? 0.f : expf(M_run - M_new);
+    float o = o_run * alpha;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const float wu = __shfl(w, half + 2 * u, 64);            // 0 for partials beyond n_act
+        o = fmaf(v[u], wu, o);
+    }
+    o_run = o;
+    l_run = l_run * alpha + l_blk;
+    M_run = M_new;
+}
+
 template <int D>
 __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
     const int CHUNK = a.chunk;
-    constexpr int W = D + 2, NP = 64, PER = NP / 2;
+    constexpr int W = D + 2;
     __shared__ float half1[128];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int n_act = (attn_len(a, b) + CHUNK - 1) / CHUNK;
@@ -368,30 +399,13 @@ __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
     const int c = tid & 127, half = tid >> 7;          // half is wave-uniform (waves 0,1 -> 0; waves 2,3 -> 1)
     const int cc = min(c, D - 1);
     float M_run = -INFINITY, l_run = 0.f, o_run = 0.f;
-    for (int base = 0; base < n_act; base += NP) {
-        float v[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int sidx = min(base + half + 2 * u, n_act - 1);   // clamped: loads stay unconditional
-            v[u] = pb[sidx * W + 2 + cc];
-        }
-        const int sl = base + lane;
-        const bool act = sl < n_act;
-        const float m_s = act ? pb[sl * W] : -INFINITY;
-        const float l_s = act ? pb[sl * W + 1] : 0.f;
-        const float M_new = fmaxf(M_run, wave_max(m_s));
-        const float w = act ? expf(m_s - M_new) : 0.f;
-        const float l_blk = wave_sum(l_s * w);
-        const float alpha = (M_run == -INFINITY) ? 0.f : expf(M_run - M_new);
-        float o = o_run * alpha;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const float wu = __shfl(w, half + 2 * u, 64);         // 0 for partials beyond n_act
-            o = fmaf(v[u], wu, o);
-        }
-        o_run = o;
-        l_run = l_run * alpha + l_blk;
-        M_run = M_new;
+    int base = 0;
+    while (base < n_act) {
+        const int rem = n_act - base;
+        if (rem <= 16) { combine_pass<D, 8>(pb, base, n_act, cc, half, lane, M_run, l_run, o_run); base += 16; }
+        else if (rem <= 32) { combine_pass<D, 16>(pb, base, n_act, cc, half, lane, M_run, l_run, o_run); base += 32; }
+        else if (rem <= 48) { combine_pass<D, 24>(pb, base, n_act, cc, half, lane, M_run, l_run, o_run); base += 48; }
+        else { combine_pass<D, 32>(pb, base, n_act, cc, half, lane, M_run, l_run, o_run); base += 64; }
     }
     if (half == 1) half1[c] = o_run;
     __syncthreads();

@@ -1,0 +1,173 @@
+// Flash-style attention in EXACT fp32 on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain at
+// the fp32 vector rate) for the once-per-sample work of the hot path:
+//   * the causal self-attention of the 2050-token prefill (core/transformer/modeling_opt.py:229 ->
+//     core/transformer/attention.py:27-62 with N == M), head_dim 96;
+//   * the point encoder's cross-attention of 2048 learned queries over the N points
+//     (core/transformer/point.py:108-126 -> attention.py, non-causal), head_dim 64.
+// softmax(Q K^T / sqrt(D) [+ causal mask]) V without materialising the [H, N, M] score matrix that the round-1 path wrote
+// and re-read per sample (271 MB at S = 2050; 537 MB for the encoder at N = 4096): the reference's own GPU path
+// (flash-attn, attention.py:44-46) never materialises it either.  All (query tile, head, sample) triples of a batch run
+// in ONE launch.
+//
+// Same transposed formulation as the fp16 kernel (k_flash_attn.h): S^T = K Q^T and O^T = V^T P^T, so that everything a
+// query needs stays in one lane column (q = lane & 31): the row max / sum need a single xor-32 exchange, the rescale
+// factor is lane-local, and the S^T accumulator registers ARE the B operand of the second product (fp32 in, no
+// repacking): MFMA step r of a 32-key block multiplies keys k0(r) (lanes 0-31) and k0(r) + 4 (lanes 32-63), exactly the
+// two keys whose probabilities sit in accumulator register r of the two lane halves.  The matrix core sums k in any
+// order, A and B only have to agree on the (lane half, step) -> k assignment; for S^T it is d = half * D/2 + step, which
+// makes the K fragment a contiguous 16-byte LDS read per four steps.
+#pragma once
+#include "er_common.h"
+
+namespace er {
+
+struct Flash32Args {
+    const float* Q; const float* K; const float* V; float* O;
+    int N, M;                               // queries, keys per (sample, head)
+    int ldq, ldk, ldv, ldo;                 // row strides (floats)
+    long long qs_b, ks_b, vs_b, os_b;       // sample strides
+    long long qs_h, ks_h, vs_h, os_h;       // head strides
+    float sqrt_d;                           // scores are DIVIDED by sqrt(D), as the reference does (attention.py:52)
+    int causal_off;                         // CAUSAL: key j is visible to query i iff j <= i + causal_off (= M - N)
+};
+
+typedef float fa32_acc __attribute__((ext_vector_type(16)));
+constexpr int FA32_KT = 64, FA32_QW = 32;   // keys per tile, queries per wave
+
+// grid (ceil(N / 128), H, B), 256 threads: wave w owns queries [128 * tile + 32 * w, +32).  Causal launches walk the
+// query tiles from the last (longest key range) to the first so the long workgroups start first.
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(ER_WG) void flash_attn_f32_kernel(Flash32Args a) {
+    constexpr int LD = D + 4;               // LDS row stride (floats), LD/4 odd -> the 16-byte K reads of a 16-lane group hit 16 distinct 4-bank slots
+    constexpr int HD = D / 2, NDB = D / 32, F4 = D / 4;
+    static_assert(D % 32 == 0 && (LD % 8) == 4, "head_dim 64 or 96: LD/4 must be odd");
+    __shared__ __attribute__((aligned(16))) float Ks[FA32_KT * LD];   // [key][d]
+    __shared__ __attribute__((aligned(16))) float Vs[FA32_KT * LD];   // [key][d]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int q0 = qt * (ER_NWAVES * FA32_QW) + wid * FA32_QW;
+    const float* Q = a.Q + b * a.qs_b + h * a.qs_h;
+    const float* K = a.K + b * a.ks_b + h * a.ks_h;
+    const float* V = a.V + b * a.vs_b + h * a.vs_h;
+    float* O = a.O + b * a.os_b + h * a.os_h;
+
+    // Q fragment (B operand of S^T): query q0 + li, dims half * D/2 + s
+    float qreg[HD];
+    const int qi = q0 + li;
+    {
+        const float* qr = Q + (long long)min(qi, a.N - 1) * a.ldq + half * HD;
+#pragma unroll
+        for (int u = 0; u < HD / 4; ++u) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qr + 4 * u);
+            qreg[4 * u] = t.x; qreg[4 * u + 1] = t.y; qreg[4 * u + 2] = t.z; qreg[4 * u + 3] = t.w;
+        }
+    }
+    fa32_acc ot[NDB];                        // O^T: rows d = db*32 + (r&3) + 8*(r>>2) + 4*half, column q = li
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;    // l_run covers this lane half's keys only
+
+    // keys any query of this WORKGROUP can see
+    const int wg_last_q = min(a.N - 1, qt * (ER_NWAVES * FA32_QW) + ER_NWAVES * FA32_QW - 1);
+    const int kmax = CAUSAL ? min(a.M, wg_last_q + a.causal_off + 1) : a.M;
+    const int ntiles = (kmax + FA32_KT - 1) / FA32_KT;
+    const int wave_last_key = CAUSAL ? (q0 + FA32_QW - 1 + a.causal_off) : (a.M - 1);   // beyond it this wave has nothing to do
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kbase = t * FA32_KT;
+        __syncthreads();                     // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < (FA32_KT * F4) / ER_WG; ++u) {
+            const int idx = tid + ER_WG * u, key = idx / F4, c4 = idx - key * F4;
+            const int gk = min(kbase + key, a.M - 1);
+            *reinterpret_cast<f32x4*>(&Ks[key * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(K + (long long)gk * a.ldk + 4 * c4);
+            *reinterpret_cast<f32x4*>(&Vs[key * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(V + (long long)gk * a.ldv + 4 * c4);
+        }
+        __syncthreads();
+        if (kbase > wave_last_key) continue;   // wave-uniform: the barriers above are still hit by every wave
+
+        // S^T = K Q^T: two 32-key blocks; lane (li, half) holds keys kbase + kb*32 + (r&3) + 8*(r>>2) + 4*half
+        fa32_acc st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < HD / 4; ++u) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(&Ks[(kb * 32 + li) * LD + half * HD + 4 * u]);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qreg[4 * u], st[kb], 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qreg[4 * u + 1], st[kb], 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qreg[4 * u + 2], st[kb], 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qreg[4 * u + 3], st[kb], 0, 0, 0);
+            }
+        }
+        // online softmax for query li over this lane half's 32 keys of the tile
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                bool ok = key < a.M;
+                if (CAUSAL) ok = ok && key <= qi + a.causal_off;
+                const float s = ok ? st[kb][r] / a.sqrt_d : -INFINITY;
+                st[kb][r] = s;
+                mloc = fmaxf(mloc, s);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        // m_new stays -inf only for a query that has not seen any key yet (padding rows q >= N of a causal tile)
+        const float alpha = (m_new == -INFINITY) ? 1.0f : expf(m_run - m_new);   // m_run = -inf -> exp(-inf) = 0
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = (st[kb][r] == -INFINITY) ? 0.f : expf(st[kb][r] - m_new);
+                st[kb][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
+
+        // O^T += V^T P^T: step r of block kb multiplies keys kb*32 + k0(r) (+4 in the upper lane half), whose
+        // probabilities are accumulator register r of the two halves -> B = st[kb][r] as it stands
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vr = &Vs[(kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LD + li];
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+                    ot[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[db * 32], st[kb][r], ot[db], 0, 0, 0);
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (qi < a.N) {
+        float* orow = O + (long long)qi * a.ldo;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) orow[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = ot[db][r] / l_tot;
+    }
+}
+
+inline hipError_t launch_flash_attn_f32(const Flash32Args& a, int D, bool causal, int H, int B, hipStream_t st) {
+    dim3 grid((a.N + ER_NWAVES * FA32_QW - 1) / (ER_NWAVES * FA32_QW), H, B);
+    if (D == 96 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<96, true>), grid, dim3(ER_WG), 0, st, a);
+    else if (D == 96) hipLaunchKernelGGL((flash_attn_f32_kernel<96, false>), grid, dim3(ER_WG), 0, st, a);
+    else if (D == 64 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<64, true>), grid, dim3(ER_WG), 0, st, a);
+    else if (D == 64) hipLaunchKernelGGL((flash_attn_f32_kernel<64, false>), grid, dim3(ER_WG), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace er

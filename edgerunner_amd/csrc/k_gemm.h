@@ -6,7 +6,7 @@
 //
 //   C[M,N] = epilogue( A[M,K] . op(B) )       op(B) = B^T for B [N,K] (nn.Linear weight / K-cache rows)
 //                                              op(B) = B   for B [K,N] (V rows, "NN")
-// Batched over blockIdx.z with two-level strides (batch, head).  Tile 128x128x16,
+// Batched over blockIdx.z with two-level strides (batch, head).  Tile 128x128x32 in two LDS stages,
 // 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32.  Operands are staged k-major
 // in LDS so that an MFMA operand fetch (lane l needs element [k = l>>5][i = l&31])
 // is a conflict-free ds_read_b32; the next k-tile is prefetched into registers while
@@ -22,6 +22,7 @@ struct GemmArgs {
     const float* A; const float* B; float* C;
     const float* bias;        // [N] or null
     const float* resid;       // [M][ldr] or null (added last)
+    int resid_mod;            // > 0: the residual has resid_mod rows and row m reads row m % resid_mod (one table shared by a batch)
     const float* gate;        // or null: per-(batch,column) multiplier applied before the residual add:
     int gate_rows;            //   v = resid + gate[(m / gate_rows) * gate_bstride + n] * (acc + bias)   (adaLN gates)
     long long gate_bstride;
@@ -42,7 +43,7 @@ struct GemmArgs {
     long long kv_bstride;
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = GBM + 4;
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBM + 4;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const
                 if (g.bias) v += g.bias[gn];
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (g.gate) v *= g.gate[(long long)(gm / g.gate_rows) * g.gate_bstride + gn];
-                if (g.resid) v += g.resid[(long long)gm * g.ldr + gn];
+                if (g.resid) v += g.resid[(long long)(g.resid_mod > 0 ? gm % g.resid_mod : gm) * g.ldr + gn];
                 if (g.epi == GEPI_PLAIN) {
                     C[(long long)gm * g.ldc + gn] = v;
                 } else {
@@ -82,8 +83,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const
 }
 
 __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
+    // two LDS stages: tile kt+1 is written while tile kt is multiplied -> ONE workgroup barrier per k-tile (round 1: two
+    // barriers per 16-wide tile kept the matrix pipe 44 % busy)
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -95,61 +98,64 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
 
     int K = g.K;
     if (g.causal && g.b_is_kn) {              // P.V: probabilities beyond the diagonal are exactly zero
-        const int klim = (m0 + GBM + g.causal_off + GBK - 1) / GBK * GBK;
+        const int klim = (m0 + GBM + g.causal_off + 15) / 16 * 16;
         K = min(K, klim);
     }
-    const int nk = K / GBK;
+    const int nk = (K + GBK - 1) / GBK;       // K % 16 == 0; a trailing half tile is zero-filled
 
-    // global -> register staging maps
-    const int ar = tid >> 2, akq = tid & 3;   // A / B(NT): row (0..63, +64), k-quad
-    const int bkr = tid >> 5, bnq = tid & 31; // B(NN): k row (0..7, +8), n-quad
-    f32x4 ra[2], rb[2];
+    // global -> register staging maps (a k-tile is GBK = 32 wide: 8 float4 per row)
+    const int ar = tid >> 3, akq = tid & 7;   // A / B(NT): row (0..31, +32 x 4), k-quad
+    const int bkr = tid >> 5, bnq = tid & 31; // B(NN): k row (0..7, +8 x 4), n-quad
+    f32x4 ra[4], rb[4];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * GBK;
+        const bool kin = k0 + 4 * akq < K;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int gm = m0 + ar + 64 * hh;
-            ra[hh] = (gm < g.M) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * akq) : zero4;
+        for (int hh = 0; hh < 4; ++hh) {
+            const int gm = m0 + ar + 32 * hh;
+            ra[hh] = (gm < g.M && kin) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * akq) : zero4;
         }
         if (!g.b_is_kn) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int gn = n0 + ar + 64 * hh;
-                rb[hh] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 4 * akq) : zero4;
+            for (int hh = 0; hh < 4; ++hh) {
+                const int gn = n0 + ar + 32 * hh;
+                rb[hh] = (gn < g.N && kin) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 4 * akq) : zero4;
             }
         } else {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < 4; ++hh) {
                 const int gk = k0 + bkr + 8 * hh;
                 const int gn = n0 + 4 * bnq;
-                rb[hh] = (gk < g.kb_valid && gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gk * g.ldb + gn) : zero4;
+                rb[hh] = (gk < g.kb_valid && gk < K && gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gk * g.ldb + gn) : zero4;
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int s) {
+        float* as = As[s];
+        float* bs = Bs[s];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int m = ar + 64 * hh;
-            As[(4 * akq + 0) * GLD + m] = ra[hh].x;
-            As[(4 * akq + 1) * GLD + m] = ra[hh].y;
-            As[(4 * akq + 2) * GLD + m] = ra[hh].z;
-            As[(4 * akq + 3) * GLD + m] = ra[hh].w;
+        for (int hh = 0; hh < 4; ++hh) {
+            const int m = ar + 32 * hh;
+            as[(4 * akq + 0) * GLD + m] = ra[hh].x;
+            as[(4 * akq + 1) * GLD + m] = ra[hh].y;
+            as[(4 * akq + 2) * GLD + m] = ra[hh].z;
+            as[(4 * akq + 3) * GLD + m] = ra[hh].w;
         }
         if (!g.b_is_kn) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int n = ar + 64 * hh;
-                Bs[(4 * akq + 0) * GLD + n] = rb[hh].x;
-                Bs[(4 * akq + 1) * GLD + n] = rb[hh].y;
-                Bs[(4 * akq + 2) * GLD + n] = rb[hh].z;
-                Bs[(4 * akq + 3) * GLD + n] = rb[hh].w;
+            for (int hh = 0; hh < 4; ++hh) {
+                const int n = ar + 32 * hh;
+                bs[(4 * akq + 0) * GLD + n] = rb[hh].x;
+                bs[(4 * akq + 1) * GLD + n] = rb[hh].y;
+                bs[(4 * akq + 2) * GLD + n] = rb[hh].z;
+                bs[(4 * akq + 3) * GLD + n] = rb[hh].w;
             }
         } else {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-                *reinterpret_cast<f32x4*>(&Bs[(bkr + 8 * hh) * GLD + 4 * bnq]) = rb[hh];
+            for (int hh = 0; hh < 4; ++hh)
+                *reinterpret_cast<f32x4*>(&bs[(bkr + 8 * hh) * GLD + 4 * bnq]) = rb[hh];
         }
     };
 
@@ -163,16 +169,17 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
 
     if (nk > 0) {
         load_tile(0);
-        store_tile();
+        store_tile(0);
     }
     __syncthreads();
     const int kh = lane >> 5, li = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < GBK / 2; ++kk) {
-            const float* ap = As + (2 * kk + kh) * GLD + wm * 64 + li;
-            const float* bp = Bs + (2 * kk + kh) * GLD + wn * 64 + li;
+            const float* ap = As[cur] + (2 * kk + kh) * GLD + wm * 64 + li;
+            const float* bp = Bs[cur] + (2 * kk + kh) * GLD + wn * 64 + li;
             const float a0 = ap[0], a1 = ap[32];
             const float b0 = bp[0], b1 = bp[32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        __syncthreads();
-        if (kt + 1 < nk) store_tile();
+        // the other stage was last read in iteration kt-1, and every wave passed that iteration's barrier since
+        if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
     }
 

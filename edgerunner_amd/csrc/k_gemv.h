@@ -111,17 +111,22 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, f
 
 // K = KS * 1536 (a wave reduces one 1536-slice = J 16-byte loads per lane, J = 6 for fp32 weights,
 // 3 for fp16).  Dynamic LDS: NB*K floats (input) + 64 floats scratch.
-template <typename WT, int KS, int NB, int RW, int PRO, int EPI>
-__global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
+// NW = waves per workgroup.  The grid should be a whole number of workgroups per CU (256 CUs): 4608 qkv rows are 768
+// workgroups of 3 waves x 2 rows (3 per CU) - with 4-wave workgroups they are 1152 (4.5 per CU: the CUs that get 5 set
+// the kernel's time) - and the 1536 out_proj rows are 512 workgroups of 3 waves x 1 row.
+template <typename WT, int KS, int NB, int RW, int PRO, int EPI, int NW = ER_NWAVES>
+__global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
+    constexpr int TPB = 64 * NW;
     constexpr int EPL = WTraits<WT>::EPL, XV = EPL / 4, SL = 1536, J = SL / (64 * EPL);
     constexpr int K = KS * SL;
-    constexpr int PT = K / ER_WG;  // elements per thread in the prologue
+    constexpr int PT = K / TPB;    // elements per thread in the prologue
+    static_assert(K % TPB == 0 && (KS == 1 || NW == ER_NWAVES), "prologue / split-K shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;              // [NB][K]
     float* red = smem + NB * K;    // 64 floats
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int slice = (KS == 1) ? 0 : wid;                 // K-slice this wave reduces
-    const int row0 = (KS == 1) ? (blockIdx.x * ER_NWAVES + wid) * RW : blockIdx.x * RW;
+    const int row0 = (KS == 1) ? (blockIdx.x * NW + wid) * RW : blockIdx.x * RW;
 
     // ---------------- loads, in the order their consumers run.  Vector loads complete in issue order (vmcnt), so the
     // small prologue / epilogue operands go FIRST and the weight stream behind them: the LayerNorm reductions then
@@ -136,17 +141,17 @@ __global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
             const float* e = a.embd + (long long)a.tok[b] * K;
             const float* p = a.posemb + (long long)a.pos[b] * K;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) { v[b][i] = e[tid + i * ER_WG]; v2[b][i] = p[tid + i * ER_WG]; }
+            for (int i = 0; i < PT; ++i) { v[b][i] = e[tid + i * TPB]; v2[b][i] = p[tid + i * TPB]; }
         }
     } else if (PRO == PRO_LN) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float* x = a.xin + (long long)b * K;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) v[b][i] = x[tid + i * ER_WG];
+            for (int i = 0; i < PT; ++i) v[b][i] = x[tid + i * TPB];
         }
 #pragma unroll
-        for (int i = 0; i < PT; ++i) { lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG]; }
+        for (int i = 0; i < PT; ++i) { lw[i] = a.ln_w[tid + i * TPB]; lb[i] = a.ln_b[tid + i * TPB]; }
     }
     // epilogue operands of the (row, batch) pairs this thread will finish
     EpiPre pre[RW][NB];
@@ -182,20 +187,20 @@ __global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < PT; ++i) s += v[b][i];
-            const float mean = block_sum_slot(s, red + 8 * b) / (float)K;
+            const float mean = block_sum_slot<NW>(s, red + 8 * b) / (float)K;
             float s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < PT; ++i) { const float d = v[b][i] - mean; s2 = fmaf(d, d, s2); }
-            const float var = block_sum_slot(s2, red + 8 * b + 4) / (float)K;
+            const float var = block_sum_slot<NW>(s2, red + 8 * b + 4) / (float)K;
             const float rstd = 1.0f / sqrtf(var + a.eps);
 #pragma unroll
             for (int i = 0; i < PT; ++i) v[b][i] = (v[b][i] - mean) * rstd * lw[i] + lb[i];
         }
 #pragma unroll
-        for (int i = 0; i < PT; ++i) xs[b * K + tid + i * ER_WG] = v[b][i];
+        for (int i = 0; i < PT; ++i) xs[b * K + tid + i * TPB] = v[b][i];
         if (PRO != PRO_NONE && a.hout != nullptr && blockIdx.x == 0) {
 #pragma unroll
-            for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * ER_WG] = v[b][i];
+            for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * TPB] = v[b][i];
         }
     }
     if (PRO != PRO_NONE) __syncthreads();
@@ -250,14 +255,14 @@ __global__ __launch_bounds__(ER_WG) void gemv_kernel(GemvArgs a) {
     }
 }
 
-template <typename WT, int KS, int NB, int RW, int PRO, int EPI>
+template <typename WT, int KS, int NB, int RW, int PRO, int EPI, int NW = ER_NWAVES>
 inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t st) {
     static_assert(KS == 1 || KS == ER_NWAVES, "K is reduced by one wave or by all four");
     constexpr int K = KS * 1536;
-    const int rows_per_block = (KS == 1) ? ER_NWAVES * RW : RW;
+    const int rows_per_block = (KS == 1) ? NW * RW : RW;
     const int grid = (a.N + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)(NB * K + 64) * sizeof(float);
-    hipLaunchKernelGGL((gemv_kernel<WT, KS, NB, RW, PRO, EPI>), dim3(grid), dim3(ER_WG), lds, st, a);
+    hipLaunchKernelGGL((gemv_kernel<WT, KS, NB, RW, PRO, EPI, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
     return hipGetLastError();
 }
 

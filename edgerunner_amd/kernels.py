@@ -73,6 +73,18 @@ def flash_attn_f16(q, k, v, heads):
     return o
 
 
+def flash_attn_f32(q, k, v, heads, causal=False):
+    """q [B,N,H*D], k/v [B,M,H*D] fp32 -> softmax(q k^T / sqrt(D) [+ causal, key j <= i + M - N]) v in exact fp32 on the
+    f32-input matrix cores, no score matrix in HBM (head_dim 64 or 96)."""
+    lib = native.load_library()
+    B, N, HD = q.shape
+    M = k.shape[1]
+    o = torch.empty_like(q)
+    native.check(lib.er_k_flash_attn_f32(native.ptr(q), native.ptr(k), native.ptr(v), native.ptr(o), B, heads, N, M, HD // heads,
+                                         int(causal), _st()), "er_k_flash_attn_f32")
+    return o
+
+
 def layernorm(x, w, b, eps=1e-5):
     lib = native.load_library()
     y = torch.empty_like(x)

@@ -238,6 +238,11 @@ int er_k_gemm_f16(const float* a_dev, const void* w_half_dev, const float* bias_
 /* softmax(q k^T / 8) v, head_dim 64, non-causal, fp16 operands / fp32 accumulate; q,o [B,N,H*64], k,v [B,M,H*64] fp32 */
 int er_k_flash_attn_f16(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch,
                         int heads, int n_queries, int m_keys, void* stream);
+/* softmax(q k^T / sqrt(D) [+ causal mask]) v in exact fp32 on the f32-input matrix cores, no score matrix in HBM
+ * (csrc/k_flash_attn_f32.h; replaces attention() of core/transformer/attention.py:27-62 for the prefill, N == M causal,
+ * head_dim 96, and for the point encoder's cross-attention, head_dim 64).  q/o: [B, N, H*D], k/v: [B, M, H*D]. */
+int er_k_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int batch, int heads, int n, int m,
+                        int head_dim, int causal, void* stream);
 int er_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
                    int rows, int cols, float eps, void* stream);
 /* rows of scores[rows, ld]: softmax over the first n_valid(row) columns (causal: row+1+causal_offset), zeros after */

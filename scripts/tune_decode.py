@@ -17,7 +17,9 @@ from edgerunner_amd.options import config_defaults  # noqa: E402
 
 T = int(os.environ.get("TUNE_TOKENS", "1000"))
 CONFIGS = [dict()] + [dict(c) for c in json.loads(os.environ.get("TUNE_CONFIGS", "[]"))]
-KNOBS = ["ER_RW_QKV", "ER_RW_FC1", "ER_RW_FC2", "ER_RW_OUT", "ER_ATTN_STEPS", "ER_NO_GRAPH", "ER_PROF_LAYERS", "ER_ATTN_V", "ER_COMBINE_V"]
+KNOBS = ["ER_RW_QKV", "ER_RW_FC1", "ER_RW_FC2", "ER_RW_OUT", "ER_ATTN_STEPS", "ER_NO_GRAPH", "ER_PROF_LAYERS", "ER_ATTN_V", "ER_COMBINE_V",
+         "ER_NW_QKV", "ER_NW_OUT", "ER_PREFILL_ATTN"]
+PRECISION = os.environ.get("TUNE_PRECISION", "fp32")
 
 
 def main():
@@ -32,18 +34,24 @@ def main():
             os.environ.pop(k, None)
         for k, v in cfg.items():
             os.environ[k] = str(v)
-        lmm = LMM(opt, "cuda:0")
+        lmm = LMM(opt, "cuda:0", precision=PRECISION)
         lmm.load_state_dict(sd, strict=True)
-        best = 0.0
+        best, pre_ms = 0.0, 1e9
         for rep in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
             _, toks = lmm.generate(pc, 1000, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+            torch.cuda.synchronize()
+            total_ms = (time.perf_counter() - t1) * 1e3
             best = max(best, T / lmm.mesh_decoder.last_decode_ms * 1e3)
+            pre_ms = min(pre_ms, total_ms - lmm.mesh_decoder.last_decode_ms)     # encode_cond + prefill + host glue
         if ref is None:
             ref = toks[0].copy()
         same = bool((toks[0] == ref).all())
-        prof = lmm.mesh_decoder.profile_decode_kernels(repeats=3)
+        prof = lmm.mesh_decoder.profile_decode_kernels(repeats=3, use_graph=True)
         per_tok = sum(v["avg_us"] * (24 if k not in ("lm_head_gemv", "sample_head") else 1) for k, v in prof.items())
-        print(json.dumps({"cfg": cfg, "decode_tok_s": round(best, 1), "ids_equal_base": same,
+        print(json.dumps({"cfg": cfg, "precision": PRECISION, "decode_tok_s": round(best, 1), "ids_equal_base": same,
+                          "encode_prefill_ms": round(pre_ms, 1),
                           "sweep_us_per_token": round(per_tok, 1),
                           "kinds_us": {k: round(v["avg_us"], 2) for k, v in prof.items()},
                           "kinds_GBps": {k: round(v["bytes"] / v["avg_us"] / 1e3, 0) for k, v in prof.items()}}), flush=True)

@@ -237,6 +237,29 @@ def test_flash_attn_f16(B, H, N, M):
     close(o, ref, 4e-3, 4e-3, "flash attention (fp16 P)")   # P is rounded to fp16 before P.V
 
 
+@pytest.mark.parametrize("B,H,N,M,D,causal", [
+    (2, 16, 2050, 2050, 96, True),        # the prefill shape (ragged last query tile and key tile)
+    (1, 16, 2048, 4096, 64, False),       # the point encoder's cross-attention
+    (2, 3, 130, 1000, 64, False),         # ragged, keys >> queries
+    (1, 2, 100, 100, 96, True), (1, 2, 70, 200, 96, True),     # causal with M > N: key j visible iff j <= i + (M - N)
+    (1, 1, 33, 1, 64, False), (1, 1, 1, 1, 96, True)])
+def test_flash_attn_f32(B, H, N, M, D, causal):
+    """Exact-fp32 fused attention (prefill / point encoder) vs an fp64 torch reference of attention()
+    (core/transformer/attention.py:47-62: scores / sqrt(D), -inf upper triangle, softmax, P V)."""
+    from edgerunner_amd import kernels as K_
+    q, k, v = rnd(B, N, H * D, seed=83), rnd(B, M, H * D, seed=84), rnd(B, M, H * D, seed=85)
+    k[:, M // 2] *= 3.0                                     # a spiky key row forces the running-max rescale
+    o = K_.flash_attn_f32(q, k, v, H, causal=causal)
+    qh, kh, vh = (t.double().view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2) / math.sqrt(D)
+    if causal:
+        i = torch.arange(N, device=DEV)[:, None]
+        j = torch.arange(M, device=DEV)[None, :]
+        sc = sc.masked_fill(j > i + (M - N), float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ vh).transpose(1, 2).reshape(B, N, H * D)
+    close(o, ref, 5e-6, 2e-5, "fp32 flash attention")
+
+
 # ------------------------------------------------------------------ row ops
 @pytest.mark.parametrize("cols", [1536, 1024])
 def test_layernorm_rows(cols):
