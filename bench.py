@@ -164,6 +164,43 @@ def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
     }
 
 
+def dit_front_end_extra(dev, steps=20):
+    """Secondary figure (BASELINE configs[4], not `value`): the image-conditioned front-end at FULL depth on this GPU in
+    the reference's GPU dtype (fp16 matrix cores): CLIP ViT-H/14 (32 layers) -> proj/norm -> DiT (24 layers, 2048 latent
+    tokens) sampled with DDIM under CFG 7.5 (batch-2 forward per step).  Compute-bound: priced against the dense fp16
+    MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  FLOPs per CFG forward are algorithmic: per layer and sample
+    36 C^2 N (projections + GEGLU MLP) + 4 N C (N + M) (self + cross attention), C = 1024, N = 2048, M = 257."""
+    import torch
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models_dit import MDiT
+    from edgerunner_amd.options import config_defaults
+    opt = dataclasses.replace(config_defaults["DiT"], generate_mode="greedy", cond_mode="point_latent")
+    m = MDiT(opt, dev, clip_layers=32, precision="fp16")
+    sd = W.make_dit_state_dict(opt, 0, "perturbed")
+    sd.update(W.make_clip_state_dict(32, 0, "perturbed"))
+    m.load_state_dict(sd, strict=True)
+    del sd
+    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(1)).to(dev)
+    out = {}
+    for _ in range(2):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        m.get_cond(img)
+        torch.cuda.synchronize(); enc = time.perf_counter() - t
+        t = time.perf_counter()
+        lat = m.run(img, num_inference_steps=steps, guidance_scale=7.5)
+        torch.cuda.synchronize(); tot = time.perf_counter() - t
+    C, N, M, L = opt.dit_hidden_dim, opt.point_latent_size, 257, opt.dit_num_layers
+    flops = 2 * L * (36.0 * C * C * N + 4.0 * N * C * (N + M))
+    per_fwd = (tot - enc) / steps
+    m.close()
+    return {"workload": f"BASELINE configs[4] front-end, full depth: CLIP ViT-H/14 32 layers + DiT {L} layers, {steps} DDIM steps, CFG 7.5, "
+                        "fp16 matrix cores, synthetic weights",
+            "clip_encode_ms": round(enc * 1e3, 2), "ms_per_cfg_forward": round(per_fwd * 1e3, 3),
+            "ms_per_100_steps": round(per_fwd * 1e5 + enc * 1e3, 1), "finite": bool(torch.isfinite(lat).all()),
+            "roofline": {"bound": "mfma", "achieved": round(flops / per_fwd / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flops / per_fwd / 2.5e15, 4), "flops_per_cfg_forward": flops}}
+
+
 def kernel_names(precision, batched):
     """rocprofv3 names of the decode kernels per kind for this build (scripts/roofline_from_rocprof.py uses the same table)."""
     wt = "float" if precision == "fp32" else "_Float16"
@@ -370,6 +407,12 @@ def main(argv=None):
             out["batch32_fp16"] = {"error": repr(e)[:200]}
         del fast
         log("fast-mode + batch-32 passes done")
+        try:
+            torch.cuda.empty_cache()
+            out["dit_front_end_fp16"] = dit_front_end_extra(dev)
+        except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the bench line
+            out["dit_front_end_fp16"] = {"error": repr(e)[:200]}
+        log("DiT front-end pass done")
     if keep_sd:
         out["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_steps, args.points)
         out["gpu_over_cpu"] = round(out["decode_only_tokens_per_s"] / out["cpu_baseline"]["value"], 1)

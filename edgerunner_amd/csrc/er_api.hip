@@ -111,9 +111,10 @@ struct er_ctx {
     bool batched_valu = false;   // ER_BATCHED_VALU=1: the older VALU kernels (one pass per 16 rows), kept for A/B runs
     float* skpart = nullptr;  // split-K partials of the batched fc2
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
-    int rw_qkv = 2, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
-    int nw_qkv = 3, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV / ER_NW_OUT: 3 or 4)
+    int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
+    int nw_qkv = 4, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV / ER_NW_OUT: 3 or 4)
     bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
+    bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -214,8 +215,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     const char* ng = getenv("ER_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
-    c->rw_qkv = env_int("ER_RW_QKV", 2);
-    c->nw_qkv = env_int("ER_NW_QKV", 3) == 4 ? 4 : 3;
+    c->rw_qkv = env_int("ER_RW_QKV", 1);
+    c->nw_qkv = env_int("ER_NW_QKV", 4) == 3 ? 3 : 4;
     c->nw_out = env_int("ER_NW_OUT", 3) == 4 ? 4 : 3;
     c->rw_fc1 = env_int("ER_RW_FC1", 2);
     c->rw_fc2 = env_int("ER_RW_FC2", 2);
@@ -223,6 +224,7 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->attn_steps = env_int("ER_ATTN_STEPS", ATTN_STEPS_DEFAULT);
     if (c->attn_steps != 2 && c->attn_steps != 8) c->attn_steps = 4;
     c->flash_prefill = env_int("ER_PREFILL_ATTN", 2) != 1;
+    c->debug_kv_flat = env_int("ER_DEBUG_KV_FLAT", 0) == 1;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
@@ -662,6 +664,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             a.q = c->qbuf;
             a.kcache = (char*)c->kc + (long long)layer * c->kv_lstride * c->kv_esz;
             a.vcache = (char*)c->vc + (long long)layer * c->kv_lstride * c->kv_esz;
+            if (c->debug_kv_flat) { a.kv_flat = 1; a.kcache = c->fbuf; a.vcache = c->fbuf + H; }
             if (layer == 0) {
                 a.embd = c->embd; a.posemb = c->posemb; a.tok = c->st.tok;
             } else {

@@ -9,6 +9,7 @@
 
 Usage:  python oracle/make_golden.py small|eos  # ~1 min each
         python oracle/make_golden.py full       # ~10 min (24 layers, T=4000)
+        python oracle/make_golden.py dit_full   # ~5 min (24 DiT + 32 CLIP layers, 3 DDIM steps)
         python oracle/make_golden.py batch      # ~6 min (24 layers, 3 rows x 3 modes x 48 steps)
 Fixtures are small .npz files; the weights are regenerated from the seed by
 ``edgerunner_amd.weights`` (never committed).
@@ -371,6 +372,41 @@ def make_batch(T=48):
     print({k: v.shape for k, v in out.items()})
 
 
+
+@torch.no_grad()
+def make_dit_full(steps=3):
+    """BASELINE configs[4] at FULL depth: the reference's own DiT module with 24 layers, fed by the 32-layer CLIP ViT-H/14
+    restatement (checked against the installed transformers CLIPVisionModel at 2 layers in make_dit), a `steps`-step
+    CFG / DDIM run from a fixed image and noise.  Kept: a few rows + checksums of cond and latents."""
+    from core.transformer.dit import DiT as RefDiT
+    opt, ref_opt = opts(2, generate_mode="greedy", cond_mode="point_latent", dit_num_layers=24)
+    t0 = time.time()
+    sd_d = W.make_dit_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE)
+    sd_d.update(W.make_clip_state_dict(32, WEIGHT_SEED, WEIGHT_STYLE))
+    dit = RefDiT(hidden_dim=opt.dit_hidden_dim, num_heads=opt.dit_num_heads, latent_size=opt.point_latent_size,
+                 latent_dim=opt.point_latent_dim, num_layers=24, gradient_checkpointing=False).eval()
+    dit.load_state_dict({k[4:]: v for k, v in sd_d.items() if k.startswith("dit.")}, strict=True)
+    g = torch.Generator().manual_seed(2718)
+    img = torch.rand(1, 3, 320, 288, generator=g)
+    noise = torch.randn(1, 2048, 64, generator=g)
+    cond = O.mdit_get_cond(sd_d, img)
+    print(f"cond in {time.time() - t0:.0f}s", flush=True)
+    lat = O.mdit_run(sd_d, cond, noise, opt.dit_num_heads, num_inference_steps=steps, guidance_scale=7.5,
+                     forward_fn=lambda a, b, c_: dit(a, b, c_))
+    print(f"latents in {time.time() - t0:.0f}s", flush=True)
+    rows = [0, 1, 1000, 2047]
+    out = {"seed": np.array([2718]), "steps": np.array([steps]), "rows": np.array(rows), "image_hw": np.array([320, 288]),
+           "cond_rows": cond[0, [0, 100, 256]].numpy(),
+           "cond_sum": np.array([float(cond.double().sum()), float(cond.double().abs().sum())]),
+           "lat_rows": lat[0, rows].numpy(), "lat_sum": np.array([float(lat.double().sum()), float(lat.double().abs().sum())])}
+    np.savez_compressed(os.path.join(GOLD, "dit_full.npz"), **out)
+    manifest_update("dit_full", {"dit_num_layers": 24, "clip_layers": 32, "steps": steps, "guidance": 7.5,
+                                 "dit": "reference DiT module (core/transformer/dit.py) on the synthetic checkpoint",
+                                 "clip": "oracle restatement of transformers 4.46.2 CLIPVisionModel (pinned at 2 layers in dit_small)",
+                                 "cases": {k: list(v.shape) for k, v in out.items()}})
+    print({k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
@@ -384,5 +420,7 @@ if __name__ == "__main__":
         make_full(int(sys.argv[2]) if len(sys.argv) > 2 else 4000)
     elif what == "batch":
         make_batch()
+    elif what == "dit_full":
+        make_dit_full()
     else:
         raise SystemExit(__doc__)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build-container helper: rebuild every HIP artefact, check that the library exports the whole header, THEN call gpurun
+# (a stale .so once cost a GPU call).  Usage: scripts/gpurun_call.sh <timeout_s> '<remote command>'
+set -e
+cd "$(dirname "$0")/.."
+python -c "import __graft_entry__ as g; g.build()" | tail -1
+for P in scripts/probes/xcd_barrier_probe scripts/probes/persistent_chain_probe; do
+  if [ ! -x $P ] || [ $P.hip -nt $P ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $P $P.hip; fi
+done
+python -m pytest tests/test_abi.py -q -x 2>&1 | tail -1
+exec /usr/local/graft/bin/gpurun --timeout "$1" -- "$2"

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void barrier_loop(BarState* s, int iters, floa
         else barrier_xcd(s, (unsigned)it, xcc, n_on_xcc, n_xcc, publish != 0);
         if (publish && threadIdx.x < 32) {
             const float v = payload[((blockIdx.x + 1) % nwg) * 32 + threadIdx.x];
-            if (v != (float)it) __hip_atomic_store((gu32*)&s->error[1], (unsigned)it, RLX_AGENT);   // stale read
+            // the neighbour may already have entered iteration it + 1 and rewritten its record (one barrier per
+            // iteration): it + 1 is fresh too; anything OLDER than `it` is a stale read
+            if (v != (float)it && v != (float)(it + 1)) __hip_atomic_store((gu32*)&s->error[1], (unsigned)it, RLX_AGENT);
             acc += v;
         }
     }

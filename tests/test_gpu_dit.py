@@ -177,3 +177,40 @@ def test_fast_mode_fp16_mfma_vs_emulation(setup):
     # the kernel's fp16 roundings (Linear inputs, q/k/v, p) sit on rounding boundaries the emulation's slightly
     # different fp32 sums can flip; 4 CFG-7.5 steps amplify those flips to a few 1e-3 on O(1) latents
     assert e_cond < 2e-3 and e_lat < 1e-2 and drift < 5e-2
+
+
+def test_full_depth_24_dit_32_clip_layers_vs_reference_golden():
+    """BASELINE configs[4] at FULL depth: image -> CLIP ViT-H/14 (32 layers) -> proj/norm -> DiT (24
+    layers) under CFG 7.5 / DDIM, 3 steps, exact fp32, against tests/golden/dit_full.npz (the reference's own DiT module
+    at 24 layers + the 32-layer CLIP restatement, oracle/make_golden.py dit_full).  fp32 vs fp32: the only differences
+    are summation orders, amplified by 24 + 32 layers and three guided steps - measured and printed, asserted at 5e-3 on
+    O(1) latents."""
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models_dit import MDiT
+    from edgerunner_amd.options import config_defaults
+    path = os.path.join(os.path.dirname(GOLD), "dit_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("full-depth DiT golden not generated")
+    g = dict(np.load(path))
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=2, generate_mode="greedy", cond_mode="point_latent",
+                              dit_num_layers=24)
+    sd = W.make_dit_state_dict(opt, 0, "perturbed")
+    sd.update(W.make_clip_state_dict(32, 0, "perturbed"))
+    m = MDiT(opt, DEV, clip_layers=32)
+    m.load_state_dict(sd, strict=True)
+    gen = torch.Generator().manual_seed(int(g["seed"][0]))
+    h, w = (int(v) for v in g["image_hw"])
+    img = torch.rand(1, 3, h, w, generator=gen)
+    noise = torch.randn(1, 2048, 64, generator=gen)
+    cond = m.get_cond(img.to(DEV))
+    e_cond = float(np.abs(cond[0, [0, 100, 256]].cpu().numpy() - g["cond_rows"]).max())
+    r_cond = abs(float(cond.double().sum()) - g["cond_sum"][0]) / g["cond_sum"][1]
+    lat = m.run(img.to(DEV), num_inference_steps=int(g["steps"][0]), guidance_scale=7.5, noise=noise.to(DEV))
+    rows = g["rows"].tolist()
+    e_lat = float(np.abs(lat[0, rows].cpu().numpy() - g["lat_rows"]).max())
+    r_lat = abs(float(lat.double().sum()) - g["lat_sum"][0]) / g["lat_sum"][1]
+    print(f"full depth (32 CLIP + 24 DiT layers, {int(g['steps'][0])} steps): cond max abs err {e_cond:.3e} (checksum rel {r_cond:.1e}); "
+          f"latents max abs err {e_lat:.3e} (checksum rel {r_lat:.1e})")
+    assert e_cond < 1e-3 and r_cond < 1e-5
+    assert e_lat < 5e-3 and r_lat < 1e-4
+    m.close()

@@ -166,3 +166,57 @@ def test_ddim_schedule_and_img2img_noise_level():
     x0 = a_t.sqrt() * s - (1 - a_t).sqrt() * v
     eps = a_t.sqrt() * v + (1 - a_t).sqrt() * s
     assert torch.allclose(out, a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps)
+
+
+def test_ddim_restatement_pinned_by_closed_forms():
+    """diffusers is absent (third-party, requirements.txt `diffusers`), so the restated DDIMScheduler of
+    core/models_dit.py:91-102 (v_prediction, scaled_linear 0.00085..0.012, 1000 train steps, leading spacing,
+    steps_offset 1, set_alpha_to_one False, eta 0, no clipping) is pinned by INDEPENDENT derivations instead:
+      1. the schedule recomputed in float64 from its definition, beta_i = (sqrt(b0) + i/(T-1) (sqrt(b1) - sqrt(b0)))^2,
+         abar_t = prod_{i<=t} (1 - beta_i), must match the fp32 table to fp32 round-off;
+      2. with cos(phi_t) = sqrt(abar_t), sin(phi_t) = sqrt(1 - abar_t), a deterministic v-prediction step is the plane
+         rotation x' = cos(phi_t - phi_p) x - sin(phi_t - phi_p) v (derived by substituting x0 and eps into the DDIM update);
+      3. for a model that always predicts the v of ONE fixed clean sample x0 and noise e (v_t = cos phi_t e - sin phi_t x0),
+         the sampler started on that noisy sample x_T = cos phi_T x0 + sin phi_T e must walk exactly along that sample's
+         trajectory and end at cos phi_0 x0 + sin phi_0 e (phi_0 from final_alpha_cumprod = abar_0) - for ANY step count;
+      4. the leading / offset-1 timestep grid: 50 steps -> 981, 961, ..., 21, 1 (the well-known grid of this scheduler
+         configuration, shared with Stable Diffusion's DDIM setup), 100 steps -> 991, ..., 1.
+    The device sampler (er_dit_sample / ddim_cfg_step_kernel) is compared against this restatement on the GPU."""
+    T, b0, b1 = 1000, 0.00085, 0.012
+    i = np.arange(T, dtype=np.float64)
+    betas = (np.sqrt(b0) + i / (T - 1) * (np.sqrt(b1) - np.sqrt(b0))) ** 2
+    abar64 = np.cumprod(1.0 - betas)
+    for steps in (100, 50, 6, 3):
+        ts, ac, final = O.ddim_schedule(steps)
+        assert np.abs(ac.numpy().astype(np.float64) - abar64).max() < 2e-6 * 1.0
+        assert np.abs(ac.numpy().astype(np.float64) / abar64 - 1).max() < 5e-5          # relative, down to abar_T ~ 4.7e-3
+        assert ts == [k * (T // steps) + 1 for k in range(steps - 1, -1, -1)]
+        assert float(final) == float(ac[0])
+    assert O.ddim_schedule(50)[0][:3] == [981, 961, 941] and O.ddim_schedule(50)[0][-2:] == [21, 1]
+    assert 0.0046 < abar64[-1] < 0.0048 and abs(abar64[0] - (1 - b0)) < 1e-15
+    # 2. rotation identity
+    ts, ac, final = O.ddim_schedule(100)
+    g = torch.Generator().manual_seed(5)
+    x, v = torch.randn(64, generator=g, dtype=torch.float64), torch.randn(64, generator=g, dtype=torch.float64)
+    ac64 = torch.from_numpy(abar64)
+    for t in (991, 501, 11, 1):
+        prev = t - 10
+        a_t, a_p = ac64[t], (ac64[prev] if prev >= 0 else ac64[0])
+        phi_t, phi_p = torch.atan2((1 - a_t).sqrt(), a_t.sqrt()), torch.atan2((1 - a_p).sqrt(), a_p.sqrt())
+        want = torch.cos(phi_t - phi_p) * x - torch.sin(phi_t - phi_p) * v
+        got = O.ddim_step_v(x, v, t, ac64, ac64[0], 10)
+        assert torch.allclose(got, want, atol=1e-12), t
+        got32 = O.ddim_step_v(x.float(), v.float(), t, ac, final, 10)
+        assert torch.allclose(got32.double(), want, atol=5e-6), t
+    # 3. exact trajectory for a fixed (x0, e): any step count ends on the same point
+    x0, e = torch.randn(32, generator=g, dtype=torch.float64), torch.randn(32, generator=g, dtype=torch.float64)
+    phi = lambda a: torch.atan2((1 - a).sqrt(), a.sqrt())     # noqa: E731
+    end = torch.cos(phi(ac64[0])) * x0 + torch.sin(phi(ac64[0])) * e
+    for steps in (100, 20, 5):
+        ts, _, _ = O.ddim_schedule(steps)
+        ratio = T // steps
+        xt = ac64[ts[0]].sqrt() * x0 + (1 - ac64[ts[0]]).sqrt() * e
+        for t in ts:
+            vt = ac64[t].sqrt() * e - (1 - ac64[t]).sqrt() * x0
+            xt = O.ddim_step_v(xt, vt, t, ac64, ac64[0], ratio)
+        assert torch.allclose(xt, end, atol=1e-10), steps
