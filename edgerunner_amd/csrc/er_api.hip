@@ -114,6 +114,7 @@ struct er_ctx {
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     int nw_qkv = 4, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV / ER_NW_OUT: 3 or 4)
     bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
+    bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
@@ -225,6 +226,7 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     if (c->attn_steps != 2 && c->attn_steps != 8) c->attn_steps = 4;
     c->flash_prefill = env_int("ER_PREFILL_ATTN", 2) != 1;
     c->debug_kv_flat = env_int("ER_DEBUG_KV_FLAT", 0) == 1;
+    c->split_prefill = env_int("ER_PREFILL_GEMM", 2) != 1;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
@@ -761,6 +763,16 @@ static hipError_t linear(const float* A, int lda, const float* W, const float* b
     return launch_gemm(g, 1, st);
 }
 
+// fast mode: C = epilogue((A_hi + A_lo) . W_fp16^T) on the fp16 matrix cores (k_gemm.h, gemm_f16s_mfma_kernel)
+static hipError_t linear_h(const float* A, int lda, const _Float16* W, const float* bias, float* C, int ldc, int M, int N, int K,
+                           bool relu, const float* resid, int ldr, hipStream_t st) {
+    GemmArgs g = gemm_args_default();
+    g.A = A; g.B = reinterpret_cast<const float*>(W); g.C = C; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldr;
+    g.relu = relu ? 1 : 0;
+    return launch_gemm_f16s(g, st);
+}
+
 #define HIPRET(expr)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -962,7 +974,8 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
             // the cache and in the scratch the prefix attention reads
             ERCHK(ensure(c->p_qkv, (size_t)M * 3 * H));
             float* qkv = c->p_qkv.p;
-            HIPRET(linear(h, H, L.wqkv, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
+            if (c->split_prefill) HIPRET(linear_h(h, H, L.wqkv_h, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
+            else HIPRET(linear(h, H, L.wqkv, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
             hipLaunchKernelGGL(kv_scatter_half_kernel, dim3(ew_grid((long long)M * 2 * H)), dim3(ER_WG), 0, st, qkv,
                                (_Float16*)kc, (_Float16*)vc, M, S, H, D, c->Lcap, c->kv_bstride);
             HIPRET(hipGetLastError());
@@ -984,11 +997,18 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
             }
         }
         // y = h + out_proj(a); h1 = LN1(y)                               modeling_opt.py:232, 272-274
-        HIPRET(linear(a, H, L.wo, L.bo, y, H, M, H, H, false, h, H, st));
+        const bool hs = c->fast && c->split_prefill;
+        if (hs) HIPRET(linear_h(a, H, L.wo_h, L.bo, y, H, M, H, H, false, h, H, st));
+        else HIPRET(linear(a, H, L.wo, L.bo, y, H, M, H, H, false, h, H, st));
         HIPRET(launch_layernorm(y, L.ln1w, L.ln1b, h, M, H, H, H, g.ln_eps, st));
         // y = h1 + fc2(relu(fc1(h1))); h = LN2(y)                        modeling_opt.py:281-288
-        HIPRET(linear(h, H, L.w1, L.b1, f, I, M, I, H, true, nullptr, 0, st));
-        HIPRET(linear(f, I, L.w2, L.b2, y, H, M, H, I, false, h, H, st));
+        if (hs) {
+            HIPRET(linear_h(h, H, L.w1_h, L.b1, f, I, M, I, H, true, nullptr, 0, st));
+            HIPRET(linear_h(f, I, L.w2_h, L.b2, y, H, M, H, I, false, h, H, st));
+        } else {
+            HIPRET(linear(h, H, L.w1, L.b1, f, I, M, I, H, true, nullptr, 0, st));
+            HIPRET(linear(f, I, L.w2, L.b2, y, H, M, H, I, false, h, H, st));
+        }
         if (l + 1 < g.num_layers) HIPRET(launch_layernorm(y, L.ln2w, L.ln2b, h, M, H, H, H, g.ln_eps, st));
     }
     // keep the last position's pre-LN2 state: the decode head applies LN2 + lm_head to it
@@ -1340,6 +1360,16 @@ extern "C" int er_k_gemm_f16(const float* a, const void* w, const float* bias, c
     g.A = a; g.B = reinterpret_cast<const float*>(w); g.C = cc; g.bias = bias; g.resid = resid; g.M = m; g.N = n; g.K = k;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.relu = relu;
     HIPRET(launch_gemm_f16(g, (hipStream_t)stream));
+    return ER_OK;
+}
+
+extern "C" int er_k_gemm_f16s(const float* a, const void* w, const float* bias, const float* resid, float* cc, int m, int n, int k,
+                              int lda, int ldb, int ldc, int relu, void* stream) {
+    if (k % 32) return fail(ER_ERR_INVALID, "er_k_gemm_f16s: k must be a multiple of 32");
+    GemmArgs g = gemm_args_default();
+    g.A = a; g.B = reinterpret_cast<const float*>(w); g.C = cc; g.bias = bias; g.resid = resid; g.M = m; g.N = n; g.K = k;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.relu = relu;
+    HIPRET(launch_gemm_f16s(g, (hipStream_t)stream));
     return ER_OK;
 }
 

@@ -280,6 +280,99 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
     gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Split" fp16 variant for the FAST-mode prefill (fp16-stored decoder weights, fp32 activations, fp32 accumulate - the
+// arithmetic the per-token GEMV path performs): the fp32 activation is split on its way into LDS into two fp16 numbers,
+//   a = hi + lo,  hi = fp16(a),  lo = fp16(a - hi)      (|a - hi - lo| <= 2^-22 |a|: fp32-grade operand),
+// and every weight fragment is multiplied by both (two v_mfma_f32_32x32x16_f16 per fragment pair, fp16 x fp16 products
+// are exact in the fp32 accumulator).  16x the fp32 matrix rate at twice the instruction count = 8x, with results within
+// fp32 round-off of the fp32-activation product - so prefill and decode keep seeing one model and the fast-mode parity
+// tests (ids exact / logits vs the fp16-STORAGE emulation) hold unchanged.  Tile 128x128x32, two LDS stages.
+__global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[2][GBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[2][GBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][GBN * HLD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const float* A = g.A;
+    const _Float16* B = reinterpret_cast<const _Float16*>(g.B);
+    const int nk = g.K / HBK;
+    f32x4 ra[4];
+    f32x4 rb[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * HBK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
+            const int gm = m0 + row;
+            ra[u] = (gm < g.M) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * c4) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
+            const int gn = n0 + row;
+            rb[u] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
+        }
+    };
+    auto store_tile = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
+            const h16x4 hv = {(_Float16)ra[u].x, (_Float16)ra[u].y, (_Float16)ra[u].z, (_Float16)ra[u].w};
+            const h16x4 lv = {(_Float16)(ra[u].x - (float)hv[0]), (_Float16)(ra[u].y - (float)hv[1]),
+                              (_Float16)(ra[u].z - (float)hv[2]), (_Float16)(ra[u].w - (float)hv[3])};
+            *reinterpret_cast<h16x4*>(&Ah[s][row * HLD + 4 * c4]) = hv;
+            *reinterpret_cast<h16x4*>(&Al[s][row * HLD + 4 * c4]) = lv;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
+            *reinterpret_cast<f32x4*>(&Bs[s][row * HLD + 8 * c8]) = rb[u];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int kh = lane >> 5, li = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            const int ko = ks * 16 + kh * 8;
+            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + li) * HLD + ko]);
+            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + 32 + li) * HLD + ko]);
+            const h16x8 a0h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + li) * HLD + ko]);
+            const h16x8 a1h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + 32 + li) * HLD + ko]);
+            const h16x8 a0l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + li) * HLD + ko]);
+            const h16x8 a1l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + 32 + li) * HLD + ko]);
+            // the small (lo) products first, then the large ones: the accumulator sees them in increasing magnitude
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);   // the other stage was last read before the previous barrier
+        __syncthreads();
+    }
+    gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);
+}
+
 inline GemmArgs gemm_args_default() {
     GemmArgs g{};
     g.Z2 = 1;
@@ -290,6 +383,12 @@ inline GemmArgs gemm_args_default() {
 inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT only, K % 32 == 0, B = fp16 weights
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, 1);
     hipLaunchKernelGGL(gemm_f16_mfma_kernel, grid, dim3(ER_WG), 0, st, g);
+    return hipGetLastError();
+}
+
+inline hipError_t launch_gemm_f16s(const GemmArgs& g, hipStream_t st) {  // NT only, K % 32 == 0, B = fp16 weights, A split hi/lo
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, 1);
+    hipLaunchKernelGGL(gemm_f16s_mfma_kernel, grid, dim3(ER_WG), 0, st, g);
     return hipGetLastError();
 }
 

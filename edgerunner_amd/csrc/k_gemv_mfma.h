@@ -76,6 +76,42 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     for (int t = 0; t < GM_R2; ++t)
 #pragma unroll
         for (int h = 0; h < NBH; ++h) acc[t][h] = (gm_f4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(WT) == 2) {
+        // fast mode: fp16 weights go to the fp16 matrix cores as they are (v_mfma_f32_16x16x16_f16, 16x the fp32 matrix
+        // rate: the fp32-MFMA form of this loop was MFMA-issue-bound at 32 rows, 3072 cycles per wave); the fp32
+        // activations keep fp32 grade by entering as two fp16 numbers x = hi + lo (|x - hi - lo| <= 2^-22 |x|), one MFMA
+        // each.  A lane's 8 weights of a piece split into two k-groups of 4 (elements 0-3 / 4-7 of every lane): the matrix
+        // core sums k in any order, A and B only have to agree on which k sits in which (lane, element) slot.
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < NLD; ++c) {
+            h4 xh[NBH][2], xl[NBH][2];
+#pragma unroll
+            for (int h = 0; h < NBH; ++h)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xv = x[h][c][j][e];
+                        const _Float16 hi = (_Float16)xv;
+                        xh[h][j][e] = hi;
+                        xl[h][j][e] = (_Float16)(xv - (float)hi);
+                    }
+#pragma unroll
+            for (int t = 0; t < GM_R2; ++t) {
+                const f16x8 hv = __builtin_bit_cast(f16x8, w[t][c]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const h4 av = {hv[4 * j], hv[4 * j + 1], hv[4 * j + 2], hv[4 * j + 3]};
+#pragma unroll
+                    for (int h = 0; h < NBH; ++h) {
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, xl[h][j], acc[t][h], 0, 0, 0);
+                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, xh[h][j], acc[t][h], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int c = 0; c < NLD; ++c) {
         float wf[GM_R2][EPL];

@@ -62,6 +62,17 @@ def gemm_f16(a, w_half, bias=None, resid=None, relu=False):
     return c
 
 
+def gemm_f16s(a, w_half, bias=None, resid=None, relu=False):
+    """C = relu?(fp16(A) . W^T + bias) (+resid) on the fp16-input MFMA path; a fp32 [M,K], w_half fp16 [N,K]."""
+    lib = native.load_library()
+    M, K = a.shape
+    N = w_half.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    native.check(lib.er_k_gemm_f16s(native.ptr(a), native.ptr(w_half), native.ptr(bias), native.ptr(resid), native.ptr(c), M, N, K,
+                                   a.stride(0), w_half.stride(0), c.stride(0), int(relu), _st()), "er_k_gemm_f16s")
+    return c
+
+
 def flash_attn_f16(q, k, v, heads):
     """q [B,N,H*64], k/v [B,M,H*64] fp32 -> softmax(q k^T / 8) v, [B,N,H*64] (fp16 operands, fp32 accumulate)."""
     lib = native.load_library()

@@ -235,6 +235,10 @@ int er_k_gemm(const float* a_dev, const float* b_dev, const float* bias_dev, con
 /* C[M,N] = relu?(fp16(A fp32 [M,K]) . W fp16 [N,K]^T + bias) (+resid): the fp16-input MFMA GEMM (k % 32 == 0) */
 int er_k_gemm_f16(const float* a_dev, const void* w_half_dev, const float* bias_dev, const float* resid_dev,
                   float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int relu, void* stream);
+/* Same shape with the fp32 activations split into fp16 hi + lo parts on their way to the matrix cores (fp32-grade operand,
+ * two fp16 MFMAs per fragment): the fast-mode prefill Linears (fp16-stored weights x fp32 activations, fp32 accumulate). */
+int er_k_gemm_f16s(const float* a, const void* w_half, const float* bias, const float* resid, float* c, int m, int n, int k,
+                   int lda, int ldb, int ldc, int relu, void* stream);
 /* softmax(q k^T / 8) v, head_dim 64, non-causal, fp16 operands / fp32 accumulate; q,o [B,N,H*64], k,v [B,M,H*64] fp32 */
 int er_k_flash_attn_f16(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch,
                         int heads, int n_queries, int m_keys, void* stream);

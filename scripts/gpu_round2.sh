@@ -38,6 +38,13 @@ for SEC in "$@"; do
       mkdir -p gpurun_out/prof; find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
       head -12 gpurun_out/prof/*kernel_stats.csv 2>/dev/null | cut -c1-160; tail -1 gpurun_out/rocprof_bench.json | cut -c1-600
       python scripts/roofline_from_rocprof.py $(ls gpurun_out/prof/*kernel_stats.csv | head -1) gpurun_out/rocprof_bench.json 2>&1 | tee gpurun_out/roofline_check.log ;;
+    profpre)   # kernel breakdown of encode + prefill (short decode), exact and fast mode
+      for PR in fp32 fp16; do
+        rm -rf /tmp/profpre_$PR
+        (cd /tmp && TUNE_PRECISION=$PR TUNE_TOKENS=8 TUNE_CONFIGS='[]' timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profpre_$PR -o pre -- python $ROOT/scripts/tune_decode.py > $ROOT/gpurun_out/profpre_$PR.log 2>&1)
+        F=$(find /tmp/profpre_$PR -name "*kernel_stats.csv" | head -1)
+        if [ -n "$F" ]; then cp $F gpurun_out/profpre_${PR}_kernel_stats.csv; echo "--- $PR"; head -14 $F | cut -c1-170; fi
+      done ;;
     pmc)
       bash scripts/gpu_pmc.sh 2>&1 | tail -14 ;;
     probes)

@@ -225,6 +225,25 @@ def test_gemm_f16_input_mfma(M, N, K):
     assert torch.equal(K_.gemm_f16(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (2050, 4608, 1536), (2050, 1536, 6144), (514, 3072, 1024), (77, 200, 608)])
+def test_gemm_f16_split_activations(M, N, K):
+    """Split-fp16 GEMM (fast-mode prefill): fp16 weights x (hi + lo)-split fp32 activations must equal the fp32-activation
+    product to fp32 round-off - i.e. the arithmetic of the per-token GEMV path - NOT the fp16-rounded-activation product."""
+    from edgerunner_amd import kernels as K_
+    a, w = rnd(M, K, seed=74), rnd(N, K, seed=75, scale=0.05)
+    a[0, :8] = torch.tensor([1e-7, -3e-6, 2049.0, -0.33333334, 6e4, 1e-3, -1.0, 0.0], device=DEV)   # tiny / large / exact values
+    bias, resid = rnd(N, seed=76), rnd(M, N, seed=77)
+    wh = w.half()
+    ref = a.double() @ wh.double().T + bias.double()
+    c = K_.gemm_f16s(a, wh, bias, resid)
+    close(c, ref + resid.double(), 2e-6 + 1e-7 * K, 2e-6, "split fp16 gemm")
+    rounded = a.half().double() @ wh.double().T + bias.double() + resid.double()
+    if K >= 1024:   # the rounded-activation product is measurably further away: the split is doing its job
+        assert float((c.double() - ref - resid.double()).abs().max()) < 0.05 * float((rounded - ref - resid.double()).abs().max())
+    c2 = K_.gemm_f16s(a, wh, bias, None, relu=True)
+    close(c2, torch.relu(ref), 2e-6 + 1e-7 * K, 2e-6, "split fp16 gemm relu")
+
+
 @pytest.mark.parametrize("B,H,N,M", [(1, 16, 2048, 2048), (2, 16, 2048, 257), (1, 2, 100, 70), (1, 1, 33, 1)])
 def test_flash_attn_f16(B, H, N, M):
     from edgerunner_amd import kernels as K_
