@@ -114,6 +114,7 @@ struct er_ctx {
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     int nw_qkv = 4, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV / ER_NW_OUT: 3 or 4)
     bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
+    int prefetch_wgs = 64;       // merge kernel: workgroups that pull out_proj's weights into L2 meanwhile (ER_PREFETCH_OUT=0 disables)
     bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
@@ -227,6 +228,7 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->flash_prefill = env_int("ER_PREFILL_ATTN", 2) != 1;
     c->debug_kv_flat = env_int("ER_DEBUG_KV_FLAT", 0) == 1;
     c->split_prefill = env_int("ER_PREFILL_GEMM", 2) != 1;
+    c->prefetch_wgs = std::max(0, std::min(256, env_int("ER_PREFETCH_OUT", 64))) / 8 * 8;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
@@ -504,7 +506,7 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     HIPCHK(hipMalloc(&c->abuf, b * hid * 4));
     HIPCHK(hipMalloc(&c->fbuf, b * g.intermediate_dim * 4));
     HIPCHK(hipMalloc(&c->logits, b * g.vocab_size * 4));
-    HIPCHK(hipMalloc(&c->part, b * H * S * (D + 2) * 4));
+    HIPCHK(hipMalloc(&c->part, (b * H * S * (D + 2) + 64) * 4));   // + a sink word for the prefetch workgroups
     HIPCHK(hipMalloc(&c->skpart, (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
@@ -683,7 +685,20 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
         }
         case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st, c->attn_v);
-        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
+        case 2: {
+            AttnDecArgs aa = attn_args(c, layer);
+            if (B == 1 && !c->batched && c->prefetch_wgs > 0 && c->prof_len >= 0) {
+                // the out_proj GEMV that follows: workgroup j reads rows [j * nw * rw, +nw * rw) = one contiguous chunk
+                const LayerW& L = c->layers[layer];
+                const int rows = (c->nw_out == 3 ? 3 : 4) * (c->nw_out == 3 ? (c->rw_out == 1 ? 1 : 2) : (c->rw_out == 1 ? 1 : (c->rw_out == 4 ? 4 : 2)));
+                aa.pf_base = HALF ? (const void*)L.wo_h : (const void*)L.wo;
+                aa.pf_chunk_bytes = rows * H * (HALF ? 2 : 4);
+                aa.pf_nchunks = (H + rows - 1) / rows;
+                aa.pf_nwg = c->prefetch_wgs;
+                if ((long long)aa.pf_nchunks * aa.pf_chunk_bytes > (long long)H * H * (HALF ? 2 : 4)) aa.pf_nchunks -= 1;   // ragged last chunk: skip
+            }
+            return launch_attn_combine(aa, c->D, B, st, c->combine_v);
+        }
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;

@@ -77,17 +77,32 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f32_kernel(Flash32Args a) {
     const int ntiles = (kmax + FA32_KT - 1) / FA32_KT;
     const int wave_last_key = CAUSAL ? (q0 + FA32_QW - 1 + a.causal_off) : (a.M - 1);   // beyond it this wave has nothing to do
 
+    // global -> register staging of one key tile (issued a whole tile ahead: the loads of tile t+1 are in flight while
+    // tile t is multiplied; one wave per SIMD has no other wave to hide that latency behind)
+    constexpr int NST = (FA32_KT * F4) / ER_WG;
+    f32x4 kst[NST], vst[NST];
+    auto load_tile = [&](int t) {
+        const int kb0 = t * FA32_KT;
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = tid + ER_WG * u, key = idx / F4, c4 = idx - key * F4;
+            const int gk = min(kb0 + key, a.M - 1);
+            kst[u] = *reinterpret_cast<const f32x4*>(K + (long long)gk * a.ldk + 4 * c4);
+            vst[u] = *reinterpret_cast<const f32x4*>(V + (long long)gk * a.ldv + 4 * c4);
+        }
+    };
+    if (ntiles > 0) load_tile(0);
     for (int t = 0; t < ntiles; ++t) {
         const int kbase = t * FA32_KT;
         __syncthreads();                     // previous tile fully consumed
 #pragma unroll
-        for (int u = 0; u < (FA32_KT * F4) / ER_WG; ++u) {
+        for (int u = 0; u < NST; ++u) {
             const int idx = tid + ER_WG * u, key = idx / F4, c4 = idx - key * F4;
-            const int gk = min(kbase + key, a.M - 1);
-            *reinterpret_cast<f32x4*>(&Ks[key * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(K + (long long)gk * a.ldk + 4 * c4);
-            *reinterpret_cast<f32x4*>(&Vs[key * LD + 4 * c4]) = *reinterpret_cast<const f32x4*>(V + (long long)gk * a.ldv + 4 * c4);
+            *reinterpret_cast<f32x4*>(&Ks[key * LD + 4 * c4]) = kst[u];
+            *reinterpret_cast<f32x4*>(&Vs[key * LD + 4 * c4]) = vst[u];
         }
         __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
         if (kbase > wave_last_key) continue;   // wave-uniform: the barriers above are still hit by every wave
 
         // S^T = K Q^T: two 32-key blocks; lane (li, half) holds keys kbase + kb*32 + (r&3) + 8*(r>>2) + 4*half

@@ -207,8 +207,9 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) _Float16 As[GBM * HLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[GBN * HLD];
+    // two LDS stages: the next k-tile is written while the current one is multiplied (one barrier per tile)
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][GBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][GBN * HLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -233,17 +234,17 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
             rb[u] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int s) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
             h16x4 hv = {(_Float16)ra[u].x, (_Float16)ra[u].y, (_Float16)ra[u].z, (_Float16)ra[u].w};
-            *reinterpret_cast<h16x4*>(&As[row * HLD + 4 * c4]) = hv;
+            *reinterpret_cast<h16x4*>(&As[s][row * HLD + 4 * c4]) = hv;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
-            *reinterpret_cast<f32x4*>(&Bs[row * HLD + 8 * c8]) = rb[u];
+            *reinterpret_cast<f32x4*>(&Bs[s][row * HLD + 8 * c8]) = rb[u];
         }
     };
     f32x16 acc[2][2];
@@ -255,26 +256,26 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (nk > 0) {
         load_tile(0);
-        store_tile();
+        store_tile(0);
     }
     __syncthreads();
     const int kh = lane >> 5, li = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < HBK / 16; ++ks) {
             const int ko = ks * 16 + kh * 8;
-            const h16x8 a0 = *reinterpret_cast<const h16x8*>(&As[(wm * 64 + li) * HLD + ko]);
-            const h16x8 a1 = *reinterpret_cast<const h16x8*>(&As[(wm * 64 + 32 + li) * HLD + ko]);
-            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[(wn * 64 + li) * HLD + ko]);
-            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[(wn * 64 + 32 + li) * HLD + ko]);
+            const h16x8 a0 = *reinterpret_cast<const h16x8*>(&As[cur][(wm * 64 + li) * HLD + ko]);
+            const h16x8 a1 = *reinterpret_cast<const h16x8*>(&As[cur][(wm * 64 + 32 + li) * HLD + ko]);
+            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + li) * HLD + ko]);
+            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + 32 + li) * HLD + ko]);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        __syncthreads();
-        if (kt + 1 < nk) store_tile();
+        if (kt + 1 < nk) store_tile(cur ^ 1);   // the other stage was last read before the previous barrier
         __syncthreads();
     }
     gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);

@@ -231,7 +231,7 @@ def test_gemm_f16_split_activations(M, N, K):
     product to fp32 round-off - i.e. the arithmetic of the per-token GEMV path - NOT the fp16-rounded-activation product."""
     from edgerunner_amd import kernels as K_
     a, w = rnd(M, K, seed=74), rnd(N, K, seed=75, scale=0.05)
-    a[0, :8] = torch.tensor([1e-7, -3e-6, 2049.0, -0.33333334, 6e4, 1e-3, -1.0, 0.0], device=DEV)   # tiny / large / exact values
+    a[0, :8] = torch.tensor([1e-7, -3e-6, 3.0009766, -0.33333334, 12.345678, 1e-3, -1.0, 0.0], device=DEV)   # tiny values, values needing the lo part
     bias, resid = rnd(N, seed=76), rnd(M, N, seed=77)
     wh = w.half()
     ref = a.double() @ wh.double().T + bias.double()
