@@ -322,20 +322,30 @@ def main(argv=None):
     decode_only = n_items * T / (D.max_over_ranks(float(np.mean(dec_ms)), dev) / 1e3)
 
     # ---- roofline of the dominant decode kernel over the run that was timed.  The context grows linearly from
-    # L0 = prefix + 1 to L0 + T - 1 and every decode kernel's duration is affine in the context length, so the
-    # run-average duration of a kernel (what `rocprofv3 --stats` reports for the same command) is its duration at the
-    # MEAN context length: the sweep below runs the attention kernels at exactly that length (hipGraph replay of the 24
-    # launches of a kind, HIP events on the launch stream, all 24 layers' weights so nothing is cache-resident).
+    # L0 + 1 to L0 + T keys over the run.  The weight-streaming kernels do not depend on it; the attention kernels do,
+    # and NOT linearly (the number of active 128-key workgroups, n = ceil(L / 128) per head, steps against the 256 CUs),
+    # so their run-average duration - what `rocprofv3 --stats` reports for the same command - is measured as the mean over
+    # NS contexts spread evenly over the run (midpoints of NS equal segments), each a hipGraph replay of the 24 launches of
+    # a kind with HIP events on the launch stream (all 24 layers' data, so nothing is cache-resident).  `achieved` =
+    # algorithmic bytes of one launch at the MEAN context length / that mean duration.
     # scripts/roofline_from_rocprof.py recomputes `frac` from profiles/*_kernel_stats.csv and checks the two agree.
     L0 = PREFIX + args.resume_len
     mean_L = L0 + (T - 1) / 2.0 + 1.0             # keys visible to the step (incl. the token being fed), run average
     L_ref = int(round(mean_L))
     prof = lmm.mesh_decoder.profile_decode_kernels(repeats=6, context_len=L_ref, use_graph=True)
-    ends = {}
-    for tag, L in (("first", L0 + 1), ("last", L0 + T)):
+    NS = 16 if T >= 64 else 1
+    samples = []
+    for i in range(NS):
+        L = L0 + 1 + int(round((i + 0.5) * T / NS)) if NS > 1 else L_ref
         p = lmm.mesh_decoder.profile_decode_kernels(repeats=3, context_len=L, use_graph=True)
-        ends[tag] = {"context_len": L, "attn_decode_us": round(p["attn_decode"]["avg_us"], 3),
-                     "attn_combine_us": round(p["attn_combine"]["avg_us"], 3)}
+        samples.append({"context_len": L, "attn_decode_us": round(p["attn_decode"]["avg_us"], 3),
+                        "attn_combine_us": round(p["attn_combine"]["avg_us"], 3)})
+    at_mean = {k: prof[k]["avg_us"] for k in ("attn_decode", "attn_combine")}
+    for k in ("attn_decode", "attn_combine"):      # run average replaces the single point at the mean length
+        prof[k]["avg_us"] = float(np.mean([s_[k + "_us"] for s_ in samples]))
+    ends = {"at_mean_context": {"context_len": L_ref, "attn_decode_us": round(at_mean["attn_decode"], 3),
+                                "attn_combine_us": round(at_mean["attn_combine"], 3)},
+            "samples": samples}
     log("kernel sweep done")
     per_token_us = {k: v["avg_us"] * LAUNCHES_PER_TOKEN[k] for k, v in prof.items()}
     dom = max(per_token_us, key=per_token_us.get)
@@ -350,9 +360,10 @@ def main(argv=None):
         "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"),
         "bytes_per_launch": prof[dom]["bytes"], "avg_us_per_launch": round(prof[dom]["avg_us"], 3),
         "context_len_at_measurement": L_ref,
-        "note": "run-average: duration and algorithmic bytes of one launch at the mean context length of the timed run "
-                f"(contexts {L0 + 1}..{L0 + T}); reproduce with scripts/roofline_from_rocprof.py on profiles/r02_*_kernel_stats.csv",
-        "context_ends": ends,
+        "note": f"run-average: mean launch duration over {NS} contexts spread over the timed run (contexts {L0 + 1}..{L0 + T}) and "
+                "the algorithmic bytes of one launch at the mean context length; reproduce with scripts/roofline_from_rocprof.py "
+                "on profiles/r02_*_kernel_stats.csv",
+        "context_sweep": ends,
         "per_layer_kernel_sum_us": round(layer_us, 2),
         "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1),
                         "us_per_token": round(per_token_us[k], 2)} for k, v in prof.items()},

@@ -114,7 +114,6 @@ struct er_ctx {
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
     int nw_qkv = 4, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV / ER_NW_OUT: 3 or 4)
     bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
-    int prefetch_wgs = 64;       // merge kernel: workgroups that pull out_proj's weights into L2 meanwhile (ER_PREFETCH_OUT=0 disables)
     bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
@@ -122,7 +121,7 @@ struct er_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
-    Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp;
+    Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp, e_ids, e_stage;
 };
 
 constexpr int ER_MAX_BATCH = 1023;   // h_pinned holds B ints + one flag
@@ -228,7 +227,6 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->flash_prefill = env_int("ER_PREFILL_ATTN", 2) != 1;
     c->debug_kv_flat = env_int("ER_DEBUG_KV_FLAT", 0) == 1;
     c->split_prefill = env_int("ER_PREFILL_GEMM", 2) != 1;
-    c->prefetch_wgs = std::max(0, std::min(256, env_int("ER_PREFETCH_OUT", 64))) / 8 * 8;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
@@ -265,7 +263,7 @@ extern "C" int er_destroy(er_ctx* c) {
     free_kv(c);
     for (void* p : c->owned) hipFree(p);
     for (Buf* b : {&c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->p_qkv, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
-                   &c->e_q, &c->e_sc, &c->e_att, &c->e_l, &c->e_ln, &c->e_u, &c->e_g, &c->e_lat, &c->e_tmp})
+                   &c->e_q, &c->e_sc, &c->e_att, &c->e_l, &c->e_ln, &c->e_u, &c->e_g, &c->e_lat, &c->e_tmp, &c->e_ids, &c->e_stage})
         if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -312,9 +310,31 @@ static bool ends_with(const std::string& s, const char* suf) {
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+// dtype conversion on the device (round 1 converted every tensor through a host fp32 vector: 7.4 s for the 2.7 GB
+// checkpoint, most of it scalar fp16 loops)
+__device__ __forceinline__ float raw_to_f32(const void* src, int dtype, size_t i) {
+    if (dtype == ER_F32) return reinterpret_cast<const float*>(src)[i];
+    if (dtype == ER_F16) return (float)reinterpret_cast<const _Float16*>(src)[i];
+    const unsigned int u = (unsigned int)reinterpret_cast<const unsigned short*>(src)[i] << 16;      // bf16
+    return __uint_as_float(u);
+}
+__global__ void cvt_f32_kernel(const void* src, int dtype, float* dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = raw_to_f32(src, dtype, i);
+}
+// streamed decoder matrix in fast mode: the fp16 copy (round to nearest even) and an fp32 copy of the SAME rounded values
+__global__ void cvt_streamed_kernel(const void* src, int dtype, float* dst32, _Float16* dst16, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const _Float16 hv = (_Float16)raw_to_f32(src, dtype, i);
+        dst16[i] = hv;
+        dst32[i] = (float)hv;
+    }
+}
+
 extern "C" int er_load_tensor(er_ctx* c, const char* key_c, const void* data, int dtype, int ndim, const int64_t* shape,
                               int on_device) {
     if (!c || !key_c || !data || ndim < 1 || ndim > 4) return fail(ER_ERR_INVALID, "er_load_tensor: bad argument");
+    if (dtype != ER_F32 && dtype != ER_F16 && dtype != ER_BF16) return fail(ER_ERR_INVALID, "er_load_tensor: dtype %d", dtype);
     HIPCHK(hipSetDevice(c->device));
     const std::string key(key_c);
     auto it = c->need.find(key);
@@ -324,42 +344,52 @@ extern "C" int er_load_tensor(er_ctx* c, const char* key_c, const void* data, in
     for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
     const er_config& g = c->cfg;
     const int H = g.hidden_dim, I = g.intermediate_dim, PH = g.point_hidden_dim;
-    int err = 0;
-    std::vector<float> h = to_f32_host(data, dtype, n, on_device, &err);
-    if (err) return fail(ER_ERR_HIP, "er_load_tensor(%s): device read failed", key_c);
+    const size_t esz = (dtype == ER_F32) ? 4 : 2;
+    // the tensor's raw bytes on the device: the caller's buffer, or one upload into the grow-only staging block
+    const void* src = data;
+    if (!on_device) {
+        ERCHK(ensure(c->e_stage, (n * esz + 3) / 4));
+        HIPCHK(hipMemcpy(c->e_stage.p, data, n * esz, hipMemcpyHostToDevice));
+        src = c->e_stage.p;
+    }
+    const unsigned cgrid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
 
     auto expect = [&](size_t want) -> int {
         if (n != want) return fail(ER_ERR_INVALID, "er_load_tensor(%s): %zu elements, expected %zu", key_c, n, want);
         return 0;
     };
+    auto finish = [&]() -> int {          // the staging block / caller buffer may be reused as soon as we return
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->own_stream));
+        return 0;
+    };
     auto put = [&](float** dst, size_t want) -> int {   // plain copy into a fresh block
         ERCHK(expect(want));
         if (!*dst) ERCHK(dev_alloc(c, dst, want));
-        HIPCHK(hipMemcpy(*dst, h.data(), want * 4, hipMemcpyHostToDevice));
-        return 0;
+        hipLaunchKernelGGL(cvt_f32_kernel, dim3(cgrid), dim3(256), 0, c->own_stream, src, dtype, *dst, want);
+        return finish();
     };
     // streamed decoder matrix: fp32 copy (+ fp16 copy and fp16-rounded fp32 values in fast mode)
     auto put_w = [&](float** dst, _Float16** dst_h, size_t total, size_t off, size_t want) -> int {
         ERCHK(expect(want));
         if (!*dst) { ERCHK(dev_alloc(c, dst, total)); HIPCHK(hipMemset(*dst, 0, total * 4)); }
         if (c->fast) {
-            std::vector<_Float16> hh(want);
-            for (size_t i = 0; i < want; ++i) { hh[i] = (_Float16)h[i]; h[i] = (float)hh[i]; }
             if (!*dst_h) {
                 HIPCHK(hipMalloc((void**)dst_h, total * 2));
                 c->owned.push_back(*dst_h);
                 HIPCHK(hipMemset(*dst_h, 0, total * 2));
             }
-            HIPCHK(hipMemcpy(*dst_h + off, hh.data(), want * 2, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(cvt_streamed_kernel, dim3(cgrid), dim3(256), 0, c->own_stream, src, dtype, *dst + off, *dst_h + off, want);
+        } else {
+            hipLaunchKernelGGL(cvt_f32_kernel, dim3(cgrid), dim3(256), 0, c->own_stream, src, dtype, *dst + off, want);
         }
-        HIPCHK(hipMemcpy(*dst + off, h.data(), want * 4, hipMemcpyHostToDevice));
-        return 0;
+        return finish();
     };
     auto put_at = [&](float** dst, size_t total, size_t off, size_t want) -> int {   // slice of a fused block
         ERCHK(expect(want));
         if (!*dst) { ERCHK(dev_alloc(c, dst, total)); HIPCHK(hipMemset(*dst, 0, total * 4)); }
-        HIPCHK(hipMemcpy(*dst + off, h.data(), want * 4, hipMemcpyHostToDevice));
-        return 0;
+        hipLaunchKernelGGL(cvt_f32_kernel, dim3(cgrid), dim3(256), 0, c->own_stream, src, dtype, *dst + off, want);
+        return finish();
     };
 
     int rc = 0;
@@ -403,6 +433,9 @@ extern "C" int er_load_tensor(er_ctx* c, const char* key_c, const void* data, in
         const int kin = 2 * g.point_freq_dim + 3;
         c->pe_kpad = (kin + 15) / 16 * 16;
         ERCHK(expect((size_t)PH * kin));
+        int err = 0;
+        std::vector<float> h = to_f32_host(data, dtype, n, on_device, &err);     // small tensor: padded on the host
+        if (err) return fail(ER_ERR_HIP, "er_load_tensor(%s): device read failed", key_c);
         std::vector<float> padded((size_t)PH * c->pe_kpad, 0.f);
         for (int r = 0; r < PH; ++r) memcpy(&padded[(size_t)r * c->pe_kpad], &h[(size_t)r * kin], kin * 4);
         if (!c->pe_mlp_w) ERCHK(dev_alloc(c, &c->pe_mlp_w, padded.size()));
@@ -439,6 +472,11 @@ extern "C" int er_finalize_weights(er_ctx* c) {
     if (!c) return fail(ER_ERR_INVALID, "null ctx");
     for (auto& kv : c->need)
         if (!kv.second) return fail(ER_ERR_MISSING, "tensor '%s' was never loaded", kv.first.c_str());
+    if (c->e_stage.p) {                   // checkpoint complete: the upload staging block (up to one tensor) is not needed any more
+        hipFree(c->e_stage.p);
+        c->e_stage.p = nullptr;
+        c->e_stage.n = 0;
+    }
     return ER_OK;
 }
 
@@ -477,6 +515,8 @@ static int make_tiled_weights(er_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------ KV cache / workspace
+static int kv_alloc(er_ctx* c, int batch, int Lcap);
+
 extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     if (!c || batch <= 0 || max_len <= 0) return fail(ER_ERR_INVALID, "er_kv_reserve: bad argument");
     if (batch > ER_MAX_BATCH) return fail(ER_ERR_UNSUPPORTED, "er_kv_reserve: batch %d > %d (host staging buffers are sized for %d rows)", batch, ER_MAX_BATCH, ER_MAX_BATCH);
@@ -488,6 +528,13 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     if (c->B == batch && c->Lcap == Lcap) return ER_OK;
     HIPCHK(hipDeviceSynchronize());
     free_kv(c);
+    const int rc_alloc = kv_alloc(c, batch, Lcap);
+    if (rc_alloc < 0) { free_kv(c); return rc_alloc; }     // a failed hipMalloc half way leaves nothing behind
+    return ER_OK;
+}
+
+static int kv_alloc(er_ctx* c, int batch, int Lcap) {
+    const er_config& g = c->cfg;
     const int H = g.num_heads, D = c->D, hid = g.hidden_dim;
     c->kv_bstride = (long long)H * Lcap * D;
     c->kv_lstride = c->kv_bstride * batch;
@@ -506,7 +553,7 @@ extern "C" int er_kv_reserve(er_ctx* c, int batch, int max_len) {
     HIPCHK(hipMalloc(&c->abuf, b * hid * 4));
     HIPCHK(hipMalloc(&c->fbuf, b * g.intermediate_dim * 4));
     HIPCHK(hipMalloc(&c->logits, b * g.vocab_size * 4));
-    HIPCHK(hipMalloc(&c->part, (b * H * S * (D + 2) + 64) * 4));   // + a sink word for the prefetch workgroups
+    HIPCHK(hipMalloc(&c->part, b * H * S * (D + 2) * 4));
     HIPCHK(hipMalloc(&c->skpart, (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
@@ -685,20 +732,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
         }
         case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st, c->attn_v);
-        case 2: {
-            AttnDecArgs aa = attn_args(c, layer);
-            if (B == 1 && !c->batched && c->prefetch_wgs > 0 && c->prof_len >= 0) {
-                // the out_proj GEMV that follows: workgroup j reads rows [j * nw * rw, +nw * rw) = one contiguous chunk
-                const LayerW& L = c->layers[layer];
-                const int rows = (c->nw_out == 3 ? 3 : 4) * (c->nw_out == 3 ? (c->rw_out == 1 ? 1 : 2) : (c->rw_out == 1 ? 1 : (c->rw_out == 4 ? 4 : 2)));
-                aa.pf_base = HALF ? (const void*)L.wo_h : (const void*)L.wo;
-                aa.pf_chunk_bytes = rows * H * (HALF ? 2 : 4);
-                aa.pf_nchunks = (H + rows - 1) / rows;
-                aa.pf_nwg = c->prefetch_wgs;
-                if ((long long)aa.pf_nchunks * aa.pf_chunk_bytes > (long long)H * H * (HALF ? 2 : 4)) aa.pf_nchunks -= 1;   // ragged last chunk: skip
-            }
-            return launch_attn_combine(aa, c->D, B, st, c->combine_v);
-        }
+        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
@@ -927,10 +961,16 @@ extern "C" int er_embed_tokens(er_ctx* c, const int32_t* ids, int B, int R, floa
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = pick(c, stream);
     const int H = c->cfg.hidden_dim;
-    for (int i = 0; i < B * R; ++i) {
+    const int n = B * R;
+    for (int i = 0; i < n; ++i)
         if (ids[i] < 0 || ids[i] >= c->cfg.vocab_size) return fail(ER_ERR_INVALID, "token id %d out of range", ids[i]);
-        HIPCHK(hipMemcpyAsync(out + (size_t)i * H, c->embd + (size_t)ids[i] * H, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
-    }
+    // one gather launch (round 1 issued one hipMemcpyAsync per token: a 2000-token resume prefix was 2000 copies)
+    ERCHK(ensure(c->e_ids, (size_t)n));                     // grow-only int scratch (4-byte slots)
+    int* d_ids = reinterpret_cast<int*>(c->e_ids.p);
+    HIPCHK(hipMemcpyAsync(d_ids, ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(ER_WG), 0, st, c->embd, d_ids, out, n, H, (long long)H);
+    HIPRET(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));     // `ids` is caller-owned host memory
     return ER_OK;
 }
 

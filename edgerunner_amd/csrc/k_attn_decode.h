@@ -33,12 +33,6 @@ struct AttnDecArgs {
     int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS with half the steps)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
-    // merge kernel only: extra workgroups that pull the NEXT kernel's (out_proj) weights into the L2 of the XCD whose
-    // workgroups will read them, while the 16 merging workgroups sit in their latency chain and HBM is idle
-    const void* pf_base;   // null: no prefetch workgroups
-    int pf_chunk_bytes;    // bytes the next kernel's workgroup j reads: [j * chunk, (j + 1) * chunk)
-    int pf_nchunks;        // number of such workgroups
-    int pf_nwg;            // prefetch workgroups appended to the grid (multiple of 8)
 };
 
 __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
@@ -394,35 +388,11 @@ __device__ __forceinline__ void combine_pass(const float* pb, int base, int n_ac
     M_run = M_new;
 }
 
-// Workgroup b of a 1-D grid runs on XCD b % 8 (observed placement - used for speed only, nothing depends on it): prefetch
-// workgroup p therefore touches the chunks of the next kernel's workgroups j = p (mod 8).
-__device__ __forceinline__ void prefetch_next_kernel(const AttnDecArgs& a, int p, float* sink) {
-    const int tid = threadIdx.x;
-    const int x = p & 7, q = p >> 3, Q = a.pf_nwg >> 3;
-    const int per = a.pf_chunk_bytes / 16;                       // float4 per chunk
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int m = q; x + 8 * m < a.pf_nchunks; m += Q) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.pf_base) + (long long)(x + 8 * m) * a.pf_chunk_bytes);
-        for (int o = tid; o < per; o += ER_WG * 4) {
-            f32x4 v0 = src[o], v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1;
-            if (o + ER_WG < per) v1 = src[o + ER_WG];
-            if (o + 2 * ER_WG < per) v2 = src[o + 2 * ER_WG];
-            if (o + 3 * ER_WG < per) v3 = src[o + 3 * ER_WG];
-            acc += (v0 + v1) + (v2 + v3);
-        }
-    }
-    if (acc.x + acc.y + acc.z + acc.w == 1.2345678e-30f) *sink = acc.x;   // keeps the loads alive; never true in practice
-}
-
 template <int D>
 __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
     const int CHUNK = a.chunk;
     constexpr int W = D + 2;
     __shared__ float half1[128];
-    if ((int)blockIdx.x >= a.H) {                                // appended prefetch workgroups (grid.y == 1 only)
-        prefetch_next_kernel(a, (int)blockIdx.x - a.H, a.part + (long long)a.H * a.S * W);
-        return;
-    }
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int n_act = (attn_len(a, b) + CHUNK - 1) / CHUNK;
     const float* pb = a.part + ((long long)b * a.H + h) * a.S * W;
@@ -477,8 +447,7 @@ template <int D>
 inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int B, hipStream_t st, int version = 2) {
     const dim3 grid(a.H, B), blk(ER_WG);
     if (version == 2) {
-        const bool pf = a.pf_base != nullptr && B == 1 && a.pf_nwg > 0;
-        hipLaunchKernelGGL((attn_combine2_kernel<D>), dim3(a.H + (pf ? a.pf_nwg : 0), B), blk, 0, st, a);
+        hipLaunchKernelGGL((attn_combine2_kernel<D>), grid, blk, 0, st, a);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(a.S + 128 + 8) * sizeof(float);

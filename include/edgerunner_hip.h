@@ -44,6 +44,10 @@ typedef enum {
     ER_ERR_UNSUPPORTED = -5   /* configuration not built             */
 } er_status;
 
+/* Element types.  As the dtype of a CHECKPOINT tensor handed to er_load_tensor / er_dit_load_tensor all three are accepted
+ * (converted on the device).  As a context's STORAGE precision (er_config.weight_dtype / kv_dtype) two combinations are
+ * built: ER_F32 + ER_F32 (exact mode) and ER_F16 + ER_F16 (fast mode, the reference's GPU dtype); ER_BF16 storage is
+ * rejected by er_create with ER_ERR_UNSUPPORTED (the reference never runs this path in bf16). */
 typedef enum { ER_F32 = 0, ER_F16 = 1, ER_BF16 = 2 } er_dtype;
 typedef enum { ER_COND_NONE = 0, ER_COND_POINT = 1, ER_COND_POINT_LATENT = 2 } er_cond_mode;
 typedef enum { ER_GREEDY = 0, ER_SAMPLE = 1 } er_gen_mode;

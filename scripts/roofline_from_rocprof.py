@@ -49,7 +49,7 @@ def main():
     frac_prof = rf["bytes_per_launch"] / (row["avg_ns"] * 1e-9) / HBM_PEAK
     print(f"dominant kernel  : {name}")
     print(f"  rocprofv3 avg  : {row['avg_ns'] / 1e3:.3f} us over {row['calls']} launches")
-    print(f"  bench.py sweep : {rf['avg_us_per_launch']:.3f} us at context {rf['context_len_at_measurement']}")
+    print(f"  bench.py sweep : {rf['avg_us_per_launch']:.3f} us (mean over the sampled contexts of the run; mean context {rf['context_len_at_measurement']})")
     print(f"  bytes/launch   : {rf['bytes_per_launch'] / 1e6:.2f} MB (algorithmic, mean context length)")
     print(f"  frac (rocprof) : {frac_prof:.4f}    frac (bench line): {rf['frac']:.4f}")
     for kind, k in rf.get("kernels", {}).items():
