@@ -117,6 +117,8 @@ struct er_ctx {
     bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
+    int attn_grid_hs = 0;     // ER_ATTN_GRID_HS=1: attention partial kernel dispatched heads-fastest
+    int attn_v_batched = 1;   // attention partial kernel version at B > 4 (env ER_ATTN_V_BATCHED)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
@@ -229,6 +231,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->split_prefill = env_int("ER_PREFILL_GEMM", 2) != 1;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
+    c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 0) == 1 ? 1 : 0;
+    c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 1) == 2 ? 2 : 1;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -687,6 +691,7 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     a.hidden = c->cfg.hidden_dim;
     a.kv_bstride = c->kv_bstride;
     a.sqrt_d = sqrtf((float)c->D);
+    a.grid_hs = c->attn_grid_hs;
     return a;
 }
 
@@ -731,7 +736,10 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
             return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
         }
-        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st, c->attn_v);
+        // v2 holds a wave's whole K/V slice in flight (latency-bound single rows); with hundreds of workgroups per CU's
+        // worth of work (B > 4) the leaner v1 (66-74 VGPRs, 6-7 waves per SIMD) streams faster: 570 vs 636 us at B = 32, L = 18050
+        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st,
+                                           (c->batched && c->attn_v_batched == 1) ? 1 : c->attn_v);
         case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];

@@ -33,6 +33,7 @@ struct AttnDecArgs {
     int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS with half the steps)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
+    int grid_hs;           // partial kernel v2: 1 = grid (H, S, B): heads fastest, so the chunks beyond the current length (which exit at once) are dispatched LAST
 };
 
 __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
     __shared__ float wm[ER_NWAVES], wl[ER_NWAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & (LPK - 1), g = lane / LPK;
-    const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int s = a.grid_hs ? blockIdx.y : blockIdx.x, h = a.grid_hs ? blockIdx.x : blockIdx.y, b = blockIdx.z;
     const int len = attn_len(a, b);
     const int k0 = s * CHUNK;
     if (k0 >= len) return;
@@ -421,6 +422,7 @@ template <int D>
 inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv_half, int B, hipStream_t st, int version = 2) {
     const dim3 grid(a.S, a.H, B), blk(ER_WG);
     if (version == 2) {
+        const dim3 grid = a.grid_hs ? dim3(a.H, a.S, B) : dim3(a.S, a.H, B);
         if (!kv_half) {
             if (steps == 2) hipLaunchKernelGGL((attn_decode2_kernel<float, D, 2>), grid, blk, 0, st, a);
             else if (steps == 8) hipLaunchKernelGGL((attn_decode2_kernel<float, D, 8>), grid, blk, 0, st, a);
