@@ -56,7 +56,7 @@ struct LayerW {
     // fast mode (fp16 storage): *_h hold the streamed fp16 matrices; the fp32 copies then hold the SAME
     // fp16-rounded values (used by the prefill GEMMs), so prefill and decode see one model
     _Float16 *wqkv_h = nullptr, *wo_h = nullptr, *w1_h = nullptr, *w2_h = nullptr;
-    void *wqkv_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;   // tiled copies for the matrix-core batched kernels (k_gemv_mfma.h)
+    void *wqkv_t = nullptr, *wo_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;   // tiled copies for the matrix-core batched kernels (k_gemv_mfma.h)
     float *wqkv = nullptr, *bqkv = nullptr;   // fused [3*hidden][hidden] in q,k,v order
     float *wo = nullptr, *bo = nullptr, *ln1w = nullptr, *ln1b = nullptr;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *ln2w = nullptr, *ln2b = nullptr;
@@ -117,7 +117,9 @@ struct er_ctx {
     bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
-    int attn_grid_hs = 0;     // ER_ATTN_GRID_HS=1: attention partial kernel dispatched heads-fastest
+    int attn_grid_hs = 1;     // attention partial kernel (v2) dispatched heads-fastest: chunks beyond the current length exit last (ER_ATTN_GRID_HS=0: chunks fastest)
+    bool fused_ln = true;     // batched qkv / fc1: LayerNorm / embedding prologue inside the matrix-core kernel (ER_FUSED_LN=0: separate launch)
+    bool out_valu = false;    // ER_OUT_VALU=1: batched out_proj on the VALU kernel (round-1 choice)
     int attn_v_batched = 1;   // attention partial kernel version at B > 4 (env ER_ATTN_V_BATCHED)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -231,8 +233,10 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->split_prefill = env_int("ER_PREFILL_GEMM", 2) != 1;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
-    c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 0) == 1 ? 1 : 0;
+    c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 1) == 0 ? 0 : 1;
     c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 1) == 2 ? 2 : 1;
+    c->out_valu = env_int("ER_OUT_VALU", 0) == 1;
+    c->fused_ln = env_int("ER_FUSED_LN", 1) != 0;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -505,10 +509,12 @@ static int make_tiled_weights(er_ctx* c) {
     for (LayerW& L : c->layers) {
         if (c->fast) {
             ERCHK(make_tiled<_Float16>(c, L.wqkv_h, &L.wqkv_t, 3 * H, H));
+            ERCHK(make_tiled<_Float16>(c, L.wo_h, &L.wo_t, H, H));
             ERCHK(make_tiled<_Float16>(c, L.w1_h, &L.w1_t, I, H));
             ERCHK(make_tiled<_Float16>(c, L.w2_h, &L.w2_t, H, I));
         } else {
             ERCHK(make_tiled<float>(c, L.wqkv, &L.wqkv_t, 3 * H, H));
+            ERCHK(make_tiled<float>(c, L.wo, &L.wo_t, H, H));
             ERCHK(make_tiled<float>(c, L.w1, &L.w1_t, I, H));
             ERCHK(make_tiled<float>(c, L.w2, &L.w2_t, H, I));
         }
@@ -650,12 +656,14 @@ static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) 
     }
     return hipSuccess;
 }
-template <typename WT, int EPI>
+template <typename WT, int EPI, int PRO = PRO_NONE>
 static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st) {
     for (int b = 0; b < B; b += NBM) {
         const int nb = (B - b) < NBM ? (B - b) : NBM;
         GemvArgs g = a;
-        g.xin += (long long)b * K;
+        if (g.xin) g.xin += (long long)b * K;
+        if (g.hout) g.hout += (long long)b * K;
+        if (g.tok) g.tok += b;
         if (g.pos) g.pos += b;
         if (g.out) g.out += (long long)b * a.N;
         if (g.resid) g.resid += (long long)b * a.N;
@@ -663,7 +671,7 @@ static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStr
         const long long kvb = (long long)b * a.kv_bstride * (a.kv_half ? 2 : 4);
         if (g.kcache) g.kcache = (char*)g.kcache + kvb;
         if (g.vcache) g.vcache = (char*)g.vcache + kvb;
-        hipError_t e = launch_gemv_mfma<WT, EPI>(g, nb, K, part, st);
+        hipError_t e = launch_gemv_mfma<WT, EPI, PRO>(g, nb, K, part, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -726,6 +734,12 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             } else {
                 a.xin = c->ypre; a.ln_w = c->layers[layer - 1].ln2w; a.ln_b = c->layers[layer - 1].ln2b;
             }
+            if (c->batched && !c->batched_valu && c->fused_ln && HALF && layer > 0) {
+                // LayerNorm prologue inside the matrix-core kernel: no LayerNorm-rows launch (fast mode only - the fp32 kernel
+                // has no registers to spare at 16 waves per workgroup; layer 0's token + position gather keeps its own launch)
+                a.W = L.wqkv_t;
+                return gemv_mfma_groups<WT, EPI_QKV, PRO_LN>(a, B, H, c->skpart, st);
+            }
             if (c->batched) {
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
@@ -744,7 +758,9 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
-            // (48 row tiles would leave the matrix-core kernel on 48 CUs: the narrow out_proj stays on the VALU kernel)
+            // 48 row tiles of 32: the matrix-core kernel runs on 48 CUs only, but streams the matrix ONCE for 32 rows where the
+            // VALU kernel needs a pass per 16 (ER_OUT_VALU=1 keeps the latter for A/B runs)
+            if (c->batched && !c->batched_valu && !c->out_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, c->skpart, st); }
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
             return gemv_rw<WT, 1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st, c->nw_out);
         }
@@ -752,6 +768,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.w1_h : (const void*)L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
             a.hout = c->h1buf; a.out = c->fbuf;
+            if (c->batched && !c->batched_valu && c->fused_ln && HALF) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU, PRO_LN>(a, B, H, c->skpart, st); }
             if (c->batched) {
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
