@@ -202,17 +202,17 @@ def dit_front_end_extra(dev, steps=20):
 
 
 def kernel_names(precision, batched):
-    """rocprofv3 names of the decode kernels per kind for this build (scripts/roofline_from_rocprof.py uses the same table)."""
+    """rocprofv3 names of the decode kernels per kind for this build's default knobs (scripts/roofline_from_rocprof.py and
+    the PMC summary are matched on them); gemv_kernel<WT, KS, NB, RW, PRO, EPI, NW>."""
     wt = "float" if precision == "fp32" else "_Float16"
-    if batched:
-        return {"attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
-    rw = (1, 2, 2, 1) if precision == "fp32" else (2, 4, 4, 2)
-    return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, {rw[0]}, 1, 3>"],
-            "attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>", f"attn_decode_kernel<{wt}, 96, 4>"],
-            "attn_combine": ["attn_combine2_kernel<96>", "attn_combine_kernel<96>"],
-            "out_proj_gemv": [f"gemv_kernel<{wt}, 1, 1, {rw[3]}, 0, 2>"],
-            "fc1_gemv": [f"gemv_kernel<{wt}, 1, 1, {rw[1]}, 1, 1>"], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, {rw[2]}, 0, 2>"],
-            "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, {2 if precision == 'fp16' else 1}, 1, 0>"], "sample_head": ["sample_head_kernel"]}
+    if batched:     # B > 4 keeps the leaner round-1 attention kernel (er_api.hip, kind 1)
+        return {"attn_decode": [f"attn_decode_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
+    return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, 4>"],
+            "attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"],
+            "attn_combine": ["attn_combine2_kernel<96>"],
+            "out_proj_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 0, 2, 3>"],
+            "fc1_gemv": [f"gemv_kernel<{wt}, 1, 1, 2, 1, 1, 4>"], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
+            "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 0, 4>"], "sample_head": ["sample_head_kernel"]}
 
 
 def dry_run(args):

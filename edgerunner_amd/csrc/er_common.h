@@ -56,6 +56,13 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return r;
 }
 
+// v of lane (l + N) mod 16 inside the lane's own row of 16 (DPP row_ror: a plain VALU move, no LDS crossbar trip like
+// ds_bpermute).  Summing a value with its rotations by 8 (and 4) adds the lanes that sit 8 (4) apart in the row.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b, float acc) {
     acc = fmaf(a.x, b.x, acc);
     acc = fmaf(a.y, b.y, acc);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
     constexpr int KPS = ER_NWAVES * KPW;
     constexpr int CHUNK = KPS * STEPS;
     static_assert(D % (EPL * LPK) == 0, "head_dim must tile into 16-byte loads");
-    __shared__ __attribute__((aligned(16))) float ored[ER_NWAVES * D];
+    __shared__ __attribute__((aligned(16))) float ored[ER_NWAVES * 4 * D];     // [wave][row of 16 lanes][dim]
     __shared__ float wm[ER_NWAVES], wl[ER_NWAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & (LPK - 1), g = lane / LPK;
@@ -323,18 +323,21 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
         }
+    // key groups sit LPK lanes apart: add them inside each row of 16 lanes with DPP rotations (VALU, no LDS crossbar), and
+    // leave the four rows of a wave to the LDS merge below (round 2a did all of it with 36 / 96 ds_bpermutes per lane)
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-#pragma unroll
-            for (int off = LPK; off < 64; off <<= 1) o[j][e] += __shfl_xor(o[j][e], off, 64);
+            o[j][e] += row_ror<8>(o[j][e]);
+            if (LPK == 4) o[j][e] += row_ror<4>(o[j][e]);
         }
-    if (g == 0) {
+    if ((lane & 15) < LPK) {
+        float* dst = ored + (wid * 4 + (lane >> 4)) * D;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) ored[wid * D + (j * LPK + p) * EPL + e] = o[j][e];
+            for (int e = 0; e < EPL; ++e) dst[(j * LPK + p) * EPL + e] = o[j][e];
     }
     if (lane == 0) { wm[wid] = m; wl[wid] = l; }
     __syncthreads();
@@ -344,7 +347,8 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
 #pragma unroll
         for (int k = 0; k < ER_NWAVES; ++k) {
             const float w = (wm[k] == -INFINITY) ? 0.f : expf(wm[k] - M);
-            ov = fmaf(ored[k * D + tid], w, ov);
+            const float* src = ored + k * 4 * D + tid;
+            ov = fmaf((src[0] + src[D]) + (src[2 * D] + src[3 * D]), w, ov);
             lv = fmaf(wl[k], w, lv);
         }
         float* pout = a.part + (((long long)b * a.H + h) * a.S + s) * (D + 2);

@@ -92,3 +92,28 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# Job planning of the drop-in scripts (reference infer.py:99-101,136-137: serial loops path x repeat x num_face)
+def plan_jobs(paths: Sequence[str], test_repeat: int, test_num_face: Sequence[int], rank: int, world: int):
+    """-> (jobs, mine, pc_owner): every (path, repeat index, num_faces) job in the reference's loop order, the indices
+    this rank runs (block-cyclic), and for every path the ONE rank that exports its point cloud (the rank owning the
+    path's first job)."""
+    jobs = [(p, i, nf) for p in paths for i in range(test_repeat) for nf in test_num_face]
+    per_path = test_repeat * len(test_num_face)
+    pc_owner = {p: (k * per_path) % world for k, p in enumerate(paths)}
+    return jobs, shard_indices(len(jobs), rank, world), pc_owner
+
+
+def group_jobs(jobs, mine: Sequence[int], n_points_of, rows_max: int):
+    """Chunks of this rank's jobs that can share ONE batched generate() call: same face count (one bucket embedding per
+    call) and same number of points (one dense [B, N, 3] tensor), at most rows_max rows.  -> [(num_faces, [job index])]."""
+    groups = {}
+    for j in mine:
+        groups.setdefault((jobs[j][2], n_points_of(jobs[j][0])), []).append(j)
+    out = []
+    for (nf, _), members in groups.items():
+        for c0 in range(0, len(members), max(1, rows_max)):
+            out.append((nf, members[c0:c0 + max(1, rows_max)]))
+    return out

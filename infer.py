@@ -95,43 +95,38 @@ def main(argv=None):
     os.makedirs(opt.workspace, exist_ok=True)
     # the reference's serial loops (infer.py:99-101,136-137): path x repeat x num_face, here sharded block-cyclically over
     # ranks and, inside a rank, batched through the B > 1 decode path (rows are independent)
-    jobs = [(p, i, nf) for p in paths for i in range(opt.test_repeat) for nf in opt.test_num_face]
-    per_path = opt.test_repeat * len(opt.test_num_face)
-    mine = D.shard_indices(len(jobs), rank, world)
+    jobs, mine, pc_owner = D.plan_jobs(paths, opt.test_repeat, opt.test_num_face, rank, world)
     clouds = {}
     for j in mine:
         path = jobs[j][0]
         if path not in clouds:
             clouds[path] = load_points(opt, path)
-            first_job = paths.index(path) * per_path
-            if first_job % world == rank:          # exactly one rank exports the cloud of a path
-                name = os.path.splitext(os.path.basename(path))[0]
-                meshio.save_points_obj(f"{opt.workspace}/{name}_pc.obj", clouds[path])
+    for path in paths:                               # exactly one rank exports the cloud of a path
+        if pc_owner[path] == rank:
+            if path not in clouds:
+                clouds[path] = load_points(opt, path)
+            name = os.path.splitext(os.path.basename(path))[0]
+            meshio.save_points_obj(f"{opt.workspace}/{name}_pc.obj", clouds[path])
     rows_max = max_rows_per_call(opt, model, opt.test_max_seq_length, device)
-    groups = {}
-    for j in mine:                                   # one generate() call takes one face count and one cloud size
-        groups.setdefault((jobs[j][2], clouds[jobs[j][0]].shape[0]), []).append(j)
     local_streams = {}
-    for (num_faces, _), members in groups.items():
-        for c0 in range(0, len(members), rows_max):
-            chunk = members[c0:c0 + rows_max]
-            cond = torch.from_numpy(np.stack([clouds[jobs[j][0]] for j in chunk])).float().to(device)
-            t0 = time.time()
-            meshes, tokens = model.generate(cond, num_faces=num_faces, max_new_tokens=opt.test_max_seq_length,
-                                            tokenizer=tokenizer, clean=True, seed=opt.seed + 7919 * chunk[0])
-            torch.cuda.synchronize()
-            dt = time.time() - t0
-            for r, j in enumerate(chunk):
-                path, i, _ = jobs[j]
-                name = os.path.splitext(os.path.basename(path))[0]
-                toks = trim_tokens(tokens[r])
-                filename = f"{name}_{i}" + (f"_{num_faces}f" if opt.use_num_face_cond else "")
-                np.save(f"{opt.workspace}/{filename}_tokens.npy", toks)
-                if meshes[r] is not None:
-                    meshio.save_ply(f"{opt.workspace}/{filename}.ply", meshes[r][0], meshes[r][1])
-                local_streams[j] = toks
-                print(f"[INFO] Processing {path} --> {filename}.ply, {len(toks)} tokens, time = {dt:.4f}s "
-                      f"({len(chunk)} jobs in this call)")
+    for num_faces, chunk in D.group_jobs(jobs, mine, lambda p: clouds[p].shape[0], rows_max):
+        cond = torch.from_numpy(np.stack([clouds[jobs[j][0]] for j in chunk])).float().to(device)
+        t0 = time.time()
+        meshes, tokens = model.generate(cond, num_faces=num_faces, max_new_tokens=opt.test_max_seq_length,
+                                        tokenizer=tokenizer, clean=True, seed=opt.seed + 7919 * chunk[0])
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        for r, j in enumerate(chunk):
+            path, i, _ = jobs[j]
+            name = os.path.splitext(os.path.basename(path))[0]
+            toks = trim_tokens(tokens[r])
+            filename = f"{name}_{i}" + (f"_{num_faces}f" if opt.use_num_face_cond else "")
+            np.save(f"{opt.workspace}/{filename}_tokens.npy", toks)
+            if meshes[r] is not None:
+                meshio.save_ply(f"{opt.workspace}/{filename}.ply", meshes[r][0], meshes[r][1])
+            local_streams[j] = toks
+            print(f"[INFO] Processing {path} --> {filename}.ply, {len(toks)} tokens, time = {dt:.4f}s "
+                  f"({len(chunk)} jobs in this call)")
     # the one exchange of the sharded path: RCCL all-gather of the token streams (ids - 3, >= -3, so shift to >= 0)
     gathered = D.gather_token_streams([local_streams[j] + 3 for j in mine], len(jobs), device=device)
     if rank == 0:

@@ -64,3 +64,29 @@ def test_shard_indices_partition():
             flat = sorted(i for p in parts for i in p)
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_plan_and_group_jobs_cover_the_reference_loops():
+    """infer.py's sharding of the reference's serial loops (infer.py:99-101,136-137): every (path, repeat, num_face) job runs on
+    exactly one rank, one rank per path exports the cloud, and a batched call holds one face count and one cloud size."""
+    from edgerunner_amd import dist as D
+    paths = [f"in/{c}.npy" for c in "abcde"]
+    npts = {p: (300 if p.endswith("c.npy") else 512) for p in paths}
+    faces = (1000, 4000)
+    for world in (1, 2, 3, 8):
+        seen, owners = [], {}
+        for rank in range(world):
+            jobs, mine, pc_owner = D.plan_jobs(paths, 3, faces, rank, world)
+            assert jobs[:4] == [(paths[0], 0, 1000), (paths[0], 0, 4000), (paths[0], 1, 1000), (paths[0], 1, 4000)]
+            seen += mine
+            owners.update(pc_owner)
+            covered = []
+            for nf, chunk in D.group_jobs(jobs, mine, lambda p: npts[p], 4):
+                assert 1 <= len(chunk) <= 4
+                assert {jobs[j][2] for j in chunk} == {nf} and len({npts[jobs[j][0]] for j in chunk}) == 1
+                covered += chunk
+            assert sorted(covered) == sorted(mine)
+        assert sorted(seen) == list(range(len(paths) * 3 * len(faces)))
+        assert set(owners) == set(paths) and all(0 <= r < world for r in owners.values())
+        for k, p in enumerate(paths):          # the owner is the rank that runs the path's first job
+            assert owners[p] == (k * 3 * len(faces)) % world
