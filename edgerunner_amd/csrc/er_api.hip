@@ -118,7 +118,6 @@ struct er_ctx {
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_grid_hs = 1;     // attention partial kernel (v2) dispatched heads-fastest: chunks beyond the current length exit last (ER_ATTN_GRID_HS=0: chunks fastest)
-    bool fused_ln = true;     // batched qkv / fc1: LayerNorm / embedding prologue inside the matrix-core kernel (ER_FUSED_LN=0: separate launch)
     bool out_valu = false;    // ER_OUT_VALU=1: batched out_proj on the VALU kernel (round-1 choice)
     int attn_v_batched = 1;   // attention partial kernel version at B > 4 (env ER_ATTN_V_BATCHED)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
@@ -236,7 +235,6 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 1) == 0 ? 0 : 1;
     c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 1) == 2 ? 2 : 1;
     c->out_valu = env_int("ER_OUT_VALU", 0) == 1;
-    c->fused_ln = env_int("ER_FUSED_LN", 1) != 0;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -656,7 +654,7 @@ static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) 
     }
     return hipSuccess;
 }
-template <typename WT, int EPI, int PRO = PRO_NONE>
+template <typename WT, int EPI>
 static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st) {
     for (int b = 0; b < B; b += NBM) {
         const int nb = (B - b) < NBM ? (B - b) : NBM;
@@ -671,7 +669,7 @@ static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStr
         const long long kvb = (long long)b * a.kv_bstride * (a.kv_half ? 2 : 4);
         if (g.kcache) g.kcache = (char*)g.kcache + kvb;
         if (g.vcache) g.vcache = (char*)g.vcache + kvb;
-        hipError_t e = launch_gemv_mfma<WT, EPI, PRO>(g, nb, K, part, st);
+        hipError_t e = launch_gemv_mfma<WT, EPI>(g, nb, K, part, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -734,12 +732,6 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             } else {
                 a.xin = c->ypre; a.ln_w = c->layers[layer - 1].ln2w; a.ln_b = c->layers[layer - 1].ln2b;
             }
-            if (c->batched && !c->batched_valu && c->fused_ln && HALF && layer > 0) {
-                // LayerNorm prologue inside the matrix-core kernel: no LayerNorm-rows launch (fast mode only - the fp32 kernel
-                // has no registers to spare at 16 waves per workgroup; layer 0's token + position gather keeps its own launch)
-                a.W = L.wqkv_t;
-                return gemv_mfma_groups<WT, EPI_QKV, PRO_LN>(a, B, H, c->skpart, st);
-            }
             if (c->batched) {
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
@@ -768,7 +760,6 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.w1_h : (const void*)L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
             a.hout = c->h1buf; a.out = c->fbuf;
-            if (c->batched && !c->batched_valu && c->fused_ln && HALF) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU, PRO_LN>(a, B, H, c->skpart, st); }
             if (c->batched) {
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;

@@ -27,19 +27,12 @@ constexpr int GM_WAVES = 16, GM_THREADS = GM_WAVES * 64, GM_R2 = 2, GM_ROWS = 16
 
 // A workgroup = 16 waves = a 32-row tile (two 16-row A tiles per wave, sharing the X registers: X comes from L2 once
 // per 32 weight rows) x 16 K-slices of 96 = K-range 1536.  NBH = 16-row batch halves (1 or 2); SPLIT: raw partials.
-// PRO (K = 1536 only): PRO_LN / PRO_EMBED build the LayerNorm'd (resp. token + position embedded) input rows INSIDE the
-// kernel - a workgroup's 16 waves hold the whole [32][1536] input between them anyway, so the row statistics are two
-// LDS-combined reductions over data already in registers, done while the weight stream is in flight.  This removes the
-// separate one-workgroup-per-row LayerNorm launch in front of qkv and fc1 (4.8 us each at B = 32: pure launch latency).
-// Workgroup 0 stores the prologue result (the post-LN residual stream) to a.hout, as the single-row kernel does.
-template <typename WT, int NBH, int EPI, bool SPLIT, int PRO = PRO_NONE>
+template <typename WT, int NBH, int EPI, bool SPLIT>
 __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int nb_valid, int K, float* part) {
     constexpr int EPL = WTraits<WT>::EPL;            // weights per 16-byte load: 4 (fp32) or 8 (fp16)
     constexpr int NLD = GM_KW / (4 * EPL);           // loads per lane and row tile: a wave-load covers 16 rows x 4*EPL k
     constexpr int XV = EPL / 4;
     __shared__ __attribute__((aligned(16))) float red[GM_WAVES][GM_R2 * NBH][64][4];
-    __shared__ float lnred[2][GM_WAVES][16 * NBH];
-    __shared__ __attribute__((aligned(16))) float lnaff[2][PRO == PRO_LN ? GM_WAVES * GM_KW : 4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * GM_ROWS;
@@ -48,27 +41,13 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     // issue order = arrival order (vmcnt is in-order): first X (L2-resident, back within a microsecond), then the weights
     // chunk by chunk, so the MFMAs of chunk c start as soon as that chunk lands while the later chunks still stream
     f32x4 x[NBH][NLD][XV];
-    f32x4 x2[PRO == PRO_EMBED ? NBH : 1][NLD][XV];           // PRO_EMBED: position-table rows, added below
 #pragma unroll
     for (int h = 0; h < NBH; ++h) {
-        const int brow = min(h * 16 + li, nb_valid - 1);
-        const float* xp = (PRO == PRO_EMBED) ? a.embd + (long long)a.tok[brow] * K + kbase : a.xin + (long long)brow * K + kbase;
+        const float* xp = a.xin + (long long)min(h * 16 + li, nb_valid - 1) * K + kbase;
 #pragma unroll
         for (int c = 0; c < NLD; ++c)
 #pragma unroll
             for (int u = 0; u < XV; ++u) x[h][c][u] = *reinterpret_cast<const f32x4*>(xp + c * 4 * EPL + 4 * u);
-        if (PRO == PRO_EMBED) {
-            const float* pp = a.posemb + (long long)a.pos[brow] * K + kbase;
-#pragma unroll
-            for (int c = 0; c < NLD; ++c)
-#pragma unroll
-                for (int u = 0; u < XV; ++u) x2[h][c][u] = *reinterpret_cast<const f32x4*>(pp + c * 4 * EPL + 4 * u);
-        }
-    }
-    float lnw_r = 0.f, lnb_r = 0.f, lnw_r2 = 0.f, lnb_r2 = 0.f;      // affine parameters go through LDS (1536 + 1536 floats per workgroup)
-    if (PRO == PRO_LN) {
-        lnw_r = a.ln_w[tid]; lnb_r = a.ln_b[tid];
-        if (tid < GM_WAVES * GM_KW - GM_THREADS) { lnw_r2 = a.ln_w[GM_THREADS + tid]; lnb_r2 = a.ln_b[GM_THREADS + tid]; }
     }
     f32x4 w[GM_R2][NLD];
     const f32x4* wp[GM_R2];
@@ -92,73 +71,6 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     // keep every load above the first MFMA: without this the scheduler sinks the loads next to their uses to save
     // registers, and a wave then has a few hundred bytes in flight instead of its whole slice
     __builtin_amdgcn_sched_barrier(0);
-    if (PRO == PRO_EMBED) {
-#pragma unroll
-        for (int h = 0; h < NBH; ++h)
-#pragma unroll
-            for (int c = 0; c < NLD; ++c)
-#pragma unroll
-                for (int u = 0; u < XV; ++u) x[h][c][u] += x2[h][c][u];
-    }
-    if (PRO == PRO_LN) {
-        // two-pass LayerNorm of row b = 16h + li over K = 1536 = 16 waves x 4 lane quarters x 24 elements
-        float mean[NBH], rstd[NBH];
-        lnaff[0][tid] = lnw_r; lnaff[1][tid] = lnb_r;
-        if (tid < GM_WAVES * GM_KW - GM_THREADS) { lnaff[0][GM_THREADS + tid] = lnw_r2; lnaff[1][GM_THREADS + tid] = lnb_r2; }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int h = 0; h < NBH; ++h) {
-                float sacc = 0.f;
-#pragma unroll
-                for (int c = 0; c < NLD; ++c)
-#pragma unroll
-                    for (int u = 0; u < XV; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = x[h][c][u][e];
-                            if (pass == 0) sacc += v;
-                            else { const float d = v - mean[h]; sacc = fmaf(d, d, sacc); }
-                        }
-                sacc += __shfl_xor(sacc, 16, 64);
-                sacc += __shfl_xor(sacc, 32, 64);
-                if (kq == 0) lnred[pass][wid][h * 16 + li] = sacc;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int h = 0; h < NBH; ++h) {
-                float tot = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < GM_WAVES; ++wv) tot += lnred[pass][wv][h * 16 + li];
-                if (pass == 0) mean[h] = tot / (float)K;
-                else rstd[h] = 1.0f / sqrtf(tot / (float)K + a.eps);
-            }
-        }
-        // (the barriers of the reductions above also published lnaff)
-        const int kloc = wid * GM_KW + kq * EPL;             // this lane's first k inside the workgroup's 1536-wide range
-#pragma unroll
-        for (int c = 0; c < NLD; ++c)
-#pragma unroll
-            for (int u = 0; u < XV; ++u) {
-                const f32x4 gw = *reinterpret_cast<const f32x4*>(&lnaff[0][kloc + c * 4 * EPL + 4 * u]);
-                const f32x4 gb = *reinterpret_cast<const f32x4*>(&lnaff[1][kloc + c * 4 * EPL + 4 * u]);
-#pragma unroll
-                for (int h = 0; h < NBH; ++h)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[h][c][u][e] = (x[h][c][u][e] - mean[h]) * rstd[h] * gw[e] + gb[e];
-            }
-    }
-    if (PRO != PRO_NONE && a.hout != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
-#pragma unroll
-        for (int h = 0; h < NBH; ++h)
-            if (h * 16 + li < nb_valid) {
-                float* hp = a.hout + (long long)(h * 16 + li) * K + kbase;
-#pragma unroll
-                for (int c = 0; c < NLD; ++c)
-#pragma unroll
-                    for (int u = 0; u < XV; ++u) *reinterpret_cast<f32x4*>(hp + c * 4 * EPL + 4 * u) = x[h][c][u];
-            }
-    }
     gm_f4 acc[GM_R2][NBH];
 #pragma unroll
     for (int t = 0; t < GM_R2; ++t)
@@ -269,18 +181,17 @@ __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const 
 }
 
 // one pass over <= 32 rows; K = ksplit * 1536; a.W must point at the TILED copy of the matrix.  `part` must hold ksplit * nb_valid * N floats when ksplit > 1.
-template <typename WT, int EPI, int PRO = PRO_NONE>
+template <typename WT, int EPI>
 inline hipError_t launch_gemv_mfma(const GemvArgs& a, int nb_valid, int K, float* part, hipStream_t st) {
     const int ksplit = K / (GM_WAVES * GM_KW);
     if (K != ksplit * GM_WAVES * GM_KW) return hipErrorInvalidValue;
     const dim3 grid((a.N + GM_ROWS - 1) / GM_ROWS, ksplit);
     const bool two = nb_valid > 16;
     if (ksplit == 1) {
-        if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, false, PRO>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
-        else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, false, PRO>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+        if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, false>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+        else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, false>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
         return hipGetLastError();
     }
-    if (PRO != PRO_NONE) return hipErrorInvalidValue;       // the in-kernel prologue needs the whole row in one workgroup
     if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, true>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
     else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, true>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
     hipError_t e = hipGetLastError();
