@@ -45,6 +45,23 @@ for SEC in "$@"; do
         F=$(find /tmp/profpre_$PR -name "*kernel_stats.csv" | head -1)
         if [ -n "$F" ]; then cp $F gpurun_out/profpre_${PR}_kernel_stats.csv; echo "--- $PR"; head -14 $F | cut -c1-170; fi
       done ;;
+    pmcsq)     # MFMA-busy / LDS counters of encode + prefill (short decode), exact and fast mode
+      for PR in fp32 fp16; do
+        rm -rf /tmp/pmcsq_$PR
+        (cd /tmp && TUNE_PRECISION=$PR TUNE_TOKENS=4 TUNE_CONFIGS='[]' ER_NO_GRAPH=1 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pmcsq_$PR -o pmc -- python $ROOT/scripts/tune_decode.py > $ROOT/gpurun_out/pmcsq_$PR.log 2>&1)
+        python scripts/pmc_summary.py pmc $(find /tmp/pmcsq_$PR -name "*counter_collection.csv") > gpurun_out/pmcsq_$PR.json 2>> gpurun_out/pmcsq_$PR.log
+        python - <<PY
+import json
+d = json.load(open("gpurun_out/pmcsq_$PR.json"))
+for k, v in d["kernels"].items():
+    if any(t in k for t in ("gemm", "flash", "layernorm")):
+        g = {c: v[c]["mean"] for c in v if isinstance(v[c], dict)}
+        busy = g.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(g.get("GRBM_GUI_ACTIVE", 1) * 128, 1)
+        print("$PR", k[:60], "n=%d" % v["GRBM_GUI_ACTIVE"]["dispatches"], "mfma_busy=%.3f" % busy,
+              "lds_conflict/active=%.3f" % (g.get("SQ_LDS_BANK_CONFLICT", 0) / max(g.get("SQ_LDS_IDX_ACTIVE", 1), 1)),
+              "gui_active=%.0f" % g.get("GRBM_GUI_ACTIVE", 0))
+PY
+      done ;;
     pmc)
       bash scripts/gpu_pmc.sh 2>&1 | tail -14 ;;
     probes)
