@@ -85,8 +85,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const
 __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
     // two LDS stages: tile kt+1 is written while tile kt is multiplied -> ONE workgroup barrier per k-tile (round 1: two
     // barriers per 16-wide tile kept the matrix pipe 44 % busy)
-    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    // LDS row strides: the transposing (k-major) stores of a thread's float4 go to 4 rows, and the 32 lanes of a store group
+    // hold (k-quad 0..7, row 0..3): with a stride = 1 (mod 8) those 32 addresses fall into 32 different banks (stride 132
+    // put them into 8 banks: PMC showed half of all LDS cycles were bank conflicts).  The NN B tile is stored row-wise with
+    // 16-byte stores and keeps the 16-byte aligned stride.
+    constexpr int GLT = GBM + 1;
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLT];
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    const int ldbs = g.b_is_kn ? GLD : GLT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -138,19 +144,19 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
             const int m = ar + 32 * hh;
-            as[(4 * akq + 0) * GLD + m] = ra[hh].x;
-            as[(4 * akq + 1) * GLD + m] = ra[hh].y;
-            as[(4 * akq + 2) * GLD + m] = ra[hh].z;
-            as[(4 * akq + 3) * GLD + m] = ra[hh].w;
+            as[(4 * akq + 0) * GLT + m] = ra[hh].x;
+            as[(4 * akq + 1) * GLT + m] = ra[hh].y;
+            as[(4 * akq + 2) * GLT + m] = ra[hh].z;
+            as[(4 * akq + 3) * GLT + m] = ra[hh].w;
         }
         if (!g.b_is_kn) {
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
                 const int n = ar + 32 * hh;
-                bs[(4 * akq + 0) * GLD + n] = rb[hh].x;
-                bs[(4 * akq + 1) * GLD + n] = rb[hh].y;
-                bs[(4 * akq + 2) * GLD + n] = rb[hh].z;
-                bs[(4 * akq + 3) * GLD + n] = rb[hh].w;
+                bs[(4 * akq + 0) * GLT + n] = rb[hh].x;
+                bs[(4 * akq + 1) * GLT + n] = rb[hh].y;
+                bs[(4 * akq + 2) * GLT + n] = rb[hh].z;
+                bs[(4 * akq + 3) * GLT + n] = rb[hh].w;
             }
         } else {
 #pragma unroll
@@ -178,8 +184,8 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < GBK / 2; ++kk) {
-            const float* ap = As[cur] + (2 * kk + kh) * GLD + wm * 64 + li;
-            const float* bp = Bs[cur] + (2 * kk + kh) * GLD + wn * 64 + li;
+            const float* ap = As[cur] + (2 * kk + kh) * GLT + wm * 64 + li;
+            const float* bp = Bs[cur] + (2 * kk + kh) * ldbs + wn * 64 + li;
             const float a0 = ap[0], a1 = ap[32];
             const float b0 = bp[0], b1 = bp[32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -207,9 +213,11 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
-    // two LDS stages: the next k-tile is written while the current one is multiplied (one barrier per tile)
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][GBM * HLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][GBN * HLD];
+    // ONE LDS stage (20 KB): a k-tile is only 8 MFMAs (256 cycles) per wave, far shorter than a global-load round trip, so
+    // what hides that latency is the number of workgroups per CU, not a second LDS stage (a two-stage version measured
+    // slower: 21.4 vs 20.4 ms per DiT forward; PMC: the split kernel below sat at 16 % MFMA busy with two stages)
+    __shared__ __attribute__((aligned(16))) _Float16 As[1][GBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[1][GBN * HLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
     __syncthreads();
     const int kh = lane >> 5, li = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        constexpr int cur = 0;
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < HBK / 16; ++ks) {
@@ -275,7 +283,8 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);   // the other stage was last read before the previous barrier
+        __syncthreads();
+        if (kt + 1 < nk) store_tile(0);
         __syncthreads();
     }
     gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);
@@ -290,9 +299,10 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
 // fp32 round-off of the fp32-activation product - so prefill and decode keep seeing one model and the fast-mode parity
 // tests (ids exact / logits vs the fp16-STORAGE emulation) hold unchanged.  Tile 128x128x32, two LDS stages.
 __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[2][GBM * HLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Al[2][GBM * HLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][GBN * HLD];
+    // one LDS stage (30 KB -> 5 workgroups per CU): see gemm_f16_mfma_kernel
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[1][GBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[1][GBM * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[1][GBN * HLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
     __syncthreads();
     const int kh = lane >> 5, li = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        constexpr int cur = 0;
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < HBK / 16; ++ks) {
@@ -368,7 +378,8 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);   // the other stage was last read before the previous barrier
+        __syncthreads();
+        if (kt + 1 < nk) store_tile(0);
         __syncthreads();
     }
     gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);
