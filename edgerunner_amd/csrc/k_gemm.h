@@ -298,49 +298,52 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
 // are exact in the fp32 accumulator).  16x the fp32 matrix rate at twice the instruction count = 8x, with results within
 // fp32 round-off of the fp32-activation product - so prefill and decode keep seeing one model and the fast-mode parity
 // tests (ids exact / logits vs the fp16-STORAGE emulation) hold unchanged.  Tile 128x128x32, two LDS stages.
+template <int BK>
 __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
+    constexpr int LDH = BK + 8;            // halves per LDS row (16-byte reads of a 16-lane group hit 16 distinct 4-bank slots for 40 and 72)
     // one LDS stage (30 KB -> 5 workgroups per CU): see gemm_f16_mfma_kernel
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[1][GBM * HLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Al[1][GBM * HLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[1][GBN * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[1][GBM * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[1][GBM * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[1][GBN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     const float* A = g.A;
     const _Float16* B = reinterpret_cast<const _Float16*>(g.B);
-    const int nk = g.K / HBK;
-    f32x4 ra[4];
-    f32x4 rb[2];
+    const int nk = g.K / BK;
+    constexpr int NA = BK / 8, NB = BK / 16, C4 = BK / 4, C8 = BK / 8;     // float4 of A / 16-byte pieces of B per thread
+    f32x4 ra[NA];
+    f32x4 rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&](int kt) {
-        const int k0 = kt * HBK;
+        const int k0 = kt * BK;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + ER_WG * u, row = idx / C4, c4 = idx % C4;
             const int gm = m0 + row;
             ra[u] = (gm < g.M) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * c4) : zero4;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + ER_WG * u, row = idx / C8, c8 = idx % C8;
             const int gn = n0 + row;
             rb[u] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
         }
     };
     auto store_tile = [&](int s) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + ER_WG * u, row = idx / C4, c4 = idx % C4;
             const h16x4 hv = {(_Float16)ra[u].x, (_Float16)ra[u].y, (_Float16)ra[u].z, (_Float16)ra[u].w};
             const h16x4 lv = {(_Float16)(ra[u].x - (float)hv[0]), (_Float16)(ra[u].y - (float)hv[1]),
                               (_Float16)(ra[u].z - (float)hv[2]), (_Float16)(ra[u].w - (float)hv[3])};
-            *reinterpret_cast<h16x4*>(&Ah[s][row * HLD + 4 * c4]) = hv;
-            *reinterpret_cast<h16x4*>(&Al[s][row * HLD + 4 * c4]) = lv;
+            *reinterpret_cast<h16x4*>(&Ah[s][row * LDH + 4 * c4]) = hv;
+            *reinterpret_cast<h16x4*>(&Al[s][row * LDH + 4 * c4]) = lv;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
-            *reinterpret_cast<f32x4*>(&Bs[s][row * HLD + 8 * c8]) = rb[u];
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + ER_WG * u, row = idx / C8, c8 = idx % C8;
+            *reinterpret_cast<f32x4*>(&Bs[s][row * LDH + 8 * c8]) = rb[u];
         }
     };
     f32x16 acc[2][2];
@@ -360,14 +363,14 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
         constexpr int cur = 0;
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
-        for (int ks = 0; ks < HBK / 16; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             const int ko = ks * 16 + kh * 8;
-            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + li) * HLD + ko]);
-            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + 32 + li) * HLD + ko]);
-            const h16x8 a0h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + li) * HLD + ko]);
-            const h16x8 a1h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + 32 + li) * HLD + ko]);
-            const h16x8 a0l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + li) * HLD + ko]);
-            const h16x8 a1l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + 32 + li) * HLD + ko]);
+            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + li) * LDH + ko]);
+            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + 32 + li) * LDH + ko]);
+            const h16x8 a0h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + li) * LDH + ko]);
+            const h16x8 a1h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + 32 + li) * LDH + ko]);
+            const h16x8 a0l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + li) * LDH + ko]);
+            const h16x8 a1l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + 32 + li) * LDH + ko]);
             // the small (lo) products first, then the large ones: the accumulator sees them in increasing magnitude
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1, acc[0][1], 0, 0, 0);
@@ -400,7 +403,9 @@ inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT o
 
 inline hipError_t launch_gemm_f16s(const GemmArgs& g, hipStream_t st) {  // NT only, K % 32 == 0, B = fp16 weights, A split hi/lo
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, 1);
-    hipLaunchKernelGGL(gemm_f16s_mfma_kernel, grid, dim3(ER_WG), 0, st, g);
+    static const bool bk64 = [] { const char* v = getenv("ER_F16S_BK"); return v && atoi(v) == 64; }();
+    if (bk64 && g.K % 64 == 0) hipLaunchKernelGGL((gemm_f16s_mfma_kernel<64>), grid, dim3(ER_WG), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f16s_mfma_kernel<32>), grid, dim3(ER_WG), 0, st, g);
     return hipGetLastError();
 }
 
