@@ -416,6 +416,25 @@ def main(argv=None):
                                            "once per step), context 2050..2306; full-length figures in DESIGN.md section 6"}
         except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the bench line
             out["batch32_fp16"] = {"error": repr(e)[:200]}
+        # BASELINE configs[2]'s shape (B = 32, SAMPLE mode top-k 10, test_num_face = 4000, fp16) at a reduced length: the
+        # full T = 16000 run takes 150 s (profiles/r02_config3_B32_T16000_fp16_sample.log: 3.47k tok/s = 66 % of 8 TB/s)
+        try:
+            Bx, Tx = 32, 1024
+            sopt = dataclasses.replace(opt, generate_mode="sample")
+            fast.opt = sopt
+            pcs = torch.cat([W.synthetic_point_cloud(i, args.points) for i in range(Bx)]).to(dev)
+            ids = fast.generate_ids(pcs, 4000, tokenizer=object(), max_new_tokens=Tx, min_new_tokens=Tx, seed=1)
+            bms = fast.mesh_decoder.last_decode_ms
+            bb = W_ELEMS * 2 + Bx * KV_ELEMS_PER_POS * (2050 + (Tx - 1) / 2.0 + 1) * 2
+            out["config2_shape_sample_fp16"] = {
+                "aggregate_decode_tokens_per_s": round(Bx * Tx / bms * 1e3, 1), "tokens_per_row": Tx, "mode": "sample top_k=10",
+                "distinct_rows": len({tuple(r) for r in ids.cpu().numpy()[:, :64].tolist()}),
+                "hbm_frac": round(bb / (bms / Tx * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "BASELINE configs[2] shape at reduced length (context 2050..3074); full size T = 16000: "
+                        "profiles/r02_config3_B32_T16000_fp16_sample.log"}
+            fast.opt = opt
+        except Exception as e:  # noqa: BLE001
+            out["config2_shape_sample_fp16"] = {"error": repr(e)[:200]}
         del fast
         log("fast-mode + batch-32 passes done")
         try:
