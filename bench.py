@@ -365,7 +365,7 @@ def main(argv=None):
                 "on profiles/r02_*_kernel_stats.csv",
         "context_sweep": ends,
         "per_layer_kernel_sum_us": round(layer_us, 2),
-        "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1),
+        "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (max(v["avg_us"], 1e-9) * 1e-6) / 1e9, 1),
                         "us_per_token": round(per_token_us[k], 2)} for k, v in prof.items()},
         "whole_step": {"bytes_per_token": bytes_per_token,
                        "achieved_GBps": round(decode_only / world * bytes_per_token / 1e9, 1),

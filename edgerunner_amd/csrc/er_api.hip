@@ -16,6 +16,7 @@
 
 #include "er_common.h"
 #include "k_attn_decode.h"
+#include "k_outproj_merge.h"
 #include "k_gemm.h"
 #include "k_gemv.h"
 #include "k_gemv_mfma.h"
@@ -121,6 +122,10 @@ struct er_ctx {
     bool out_valu = false;    // ER_OUT_VALU=1: batched out_proj on the VALU kernel (round-1 choice)
     int attn_v_batched = 1;   // attention partial kernel version at B > 4 (env ER_ATTN_V_BATCHED)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
+    int decode_v = 2;         // ER_DECODE_V=3: balanced-chunk attention + merge fused into out_proj (single row, D = 96, 16 heads, Lcap <= 8192)
+    bool v3 = false;          // decode_v == 3 and the reserved cache qualifies
+    int nch3 = 0;             // chunks per head of the balanced attention kernel
+    float* part_ml = nullptr; // version 3: {m, l} of the partials
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
@@ -220,7 +225,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->use_graph = !(ng && ng[0] == '1');
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
     c->rw_qkv = env_int("ER_RW_QKV", 1);
-    c->nw_qkv = env_int("ER_NW_QKV", 4) == 3 ? 3 : 4;
+    c->nw_qkv = env_int("ER_NW_QKV", 4);
+    if (c->nw_qkv != 3 && c->nw_qkv != 6) c->nw_qkv = 4;
     c->nw_out = env_int("ER_NW_OUT", 3) == 4 ? 4 : 3;
     c->rw_fc1 = env_int("ER_RW_FC1", 2);
     c->rw_fc2 = env_int("ER_RW_FC2", 2);
@@ -235,6 +241,7 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 1) == 0 ? 0 : 1;
     c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 1) == 2 ? 2 : 1;
     c->out_valu = env_int("ER_OUT_VALU", 0) == 1;
+    c->decode_v = env_int("ER_DECODE_V", 2) == 3 ? 3 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -251,6 +258,8 @@ static void free_kv(er_ctx* c) {
     c->kc = c->vc = c->ypre = c->hbuf = c->ypre1 = c->h1buf = c->qbuf = c->abuf = c->fbuf = c->logits = c->part = nullptr;
     if (c->skpart) hipFree(c->skpart);
     c->skpart = nullptr;
+    if (c->part_ml) hipFree(c->part_ml);
+    c->part_ml = nullptr;
     if (c->state_block) hipFree(c->state_block);
     if (c->d_params) hipFree(c->d_params);
     if (c->d_ids_tmp) hipFree(c->d_ids_tmp);
@@ -561,7 +570,9 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     HIPCHK(hipMalloc(&c->abuf, b * hid * 4));
     HIPCHK(hipMalloc(&c->fbuf, b * g.intermediate_dim * 4));
     HIPCHK(hipMalloc(&c->logits, b * g.vocab_size * 4));
-    HIPCHK(hipMalloc(&c->part, b * H * S * (D + 2) * 4));
+    c->nch3 = attn3_num_chunks(H);
+    HIPCHK(hipMalloc(&c->part, b * H * (size_t)std::max(S * (D + 2), c->nch3 * D) * 4));
+    HIPCHK(hipMalloc(&c->part_ml, b * H * (size_t)c->nch3 * 2 * 4));
     HIPCHK(hipMalloc(&c->skpart, (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
@@ -578,6 +589,7 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     const char* bv = getenv("ER_BATCHED_VALU");
     c->batched_valu = bv && bv[0] == '1';
     if (c->batched && !c->batched_valu) ERCHK(make_tiled_weights(c));
+    c->v3 = c->decode_v == 3 && batch == 1 && !c->batched && D == 96 && H == 16 && hid == 1536 && attn3_fits(Lcap, H);
     return ER_OK;
 }
 
@@ -626,6 +638,7 @@ static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st, int 
             if (rw == 1) return gemv_groups<WT, KS, 1, PRO, EPI, 3>(a, B, K, st);
             return gemv_groups<WT, KS, 2, PRO, EPI, 3>(a, B, K, st);
         }
+        if (nw == 6) return gemv_groups<WT, KS, 1, PRO, EPI, 6>(a, B, K, st);     // 6 waves x 1 row: 4608 qkv rows = 768 workgroups
     }
     switch (rw) {
         case 1: return gemv_groups<WT, KS, 1, PRO, EPI>(a, B, K, st);
@@ -690,6 +703,7 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     a.fixed_len = c->prof_len;
     a.len_dev = nullptr;
     a.part = c->part;
+    a.part_ml = c->part_ml;
     a.out = c->abuf;
     a.H = c->cfg.num_heads;
     a.l_cap = c->Lcap;
@@ -744,11 +758,21 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
         }
         // v2 holds a wave's whole K/V slice in flight (latency-bound single rows); with hundreds of workgroups per CU's
         // worth of work (B > 4) the leaner v1 (66-74 VGPRs, 6-7 waves per SIMD) streams faster: 570 vs 636 us at B = 32, L = 18050
-        case 1: return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st,
-                                           (c->batched && c->attn_v_batched == 1) ? 1 : c->attn_v);
-        case 2: return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
+        case 1:
+            if (c->v3) return launch_attn_partial3_d<96>(attn_args(c, layer), HALF, c->nch3, B, st);
+            return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st,
+                                       (c->batched && c->attn_v_batched == 1) ? 1 : c->attn_v);
+        case 2:
+            if (c->v3) return hipSuccess;      // the merge runs inside the out_proj kernel
+            return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
+            if (c->v3) {
+                OutMergeArgs m{};
+                m.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; m.bias = L.bo; m.resid = c->hbuf; m.out = c->ypre1;
+                m.part_o = c->part; m.part_ml = c->part_ml; m.N = H;
+                return launch_outproj_merge<WT, 96>(m, c->nch3, st);
+            }
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
             // 48 row tiles of 32: the matrix-core kernel runs on 48 CUs only, but streams the matrix ONCE for 32 rows where the
             // VALU kernel needs a pass per 16 (ER_OUT_VALU=1 keeps the latter for A/B runs)
@@ -1273,8 +1297,13 @@ static int profile_impl(er_ctx* c, int repeats, int use_graph, float* avg_us, do
     bytes[6] = ((double)V * H) * w + (double)B * (H + V) * w;
     bytes[7] = (double)B * V * w;
 
+    if (c->v3) {   // the merge is part of the out_proj launch: its partial reads are charged there
+        bytes[3] += (double)g.num_heads * c->nch3 * (c->D + 2) * 4.0;
+        bytes[2] = 0.0;
+    }
     for (int kind = 0; kind < ER_NUM_KERNEL_KINDS; ++kind) {
         const bool per_layer = kind <= 5;
+        if (c->v3 && kind == 2) { avg_us[kind] = 0.f; continue; }
         // warm-up + timed sweeps
         hipGraphExec_t gexec = nullptr;
         if (use_graph && per_layer) {     // the nl launches of this kind as one replayable graph (what the generation loop replays)
@@ -1409,6 +1438,31 @@ extern "C" int er_k_attn_decode(const float* q, const void* k, const void* v, co
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(len_dev);
     hipFree(part);
+    HIPRET(e);
+    HIPRET(e2);
+    return ER_OK;
+}
+
+extern "C" int er_k_attn_outproj3(const float* q, const void* k, const void* v, int len, const void* wo, const float* bo,
+                                  const float* resid, float* y, int l_cap, int kv_half, int w_half, void* stream) {
+    // version 3 of the single-row decode attention: balanced chunks (16 heads x 16 chunks) + the merge fused into out_proj
+    constexpr int H = 16, D = 96;
+    if (len <= 0 || len > l_cap || !attn3_fits(l_cap, H)) return fail(ER_ERR_CAPACITY, "er_k_attn_outproj3: len %d / l_cap %d (<= %d)", len, l_cap, attn3_num_chunks(H) * ATTN3_CAP);
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = attn3_num_chunks(H);
+    float *part = nullptr, *part_ml = nullptr;
+    HIPCHK(hipMalloc(&part, (size_t)H * nch * D * 4));
+    HIPCHK(hipMalloc(&part_ml, (size_t)H * nch * 2 * 4));
+    AttnDecArgs a{};
+    a.q = q; a.kcache = k; a.vcache = v; a.fixed_len = len; a.part = part; a.part_ml = part_ml;
+    a.H = H; a.l_cap = l_cap; a.hidden = H * D; a.kv_bstride = (long long)H * l_cap * D; a.sqrt_d = sqrtf((float)D);
+    hipError_t e = launch_attn_partial3_d<D>(a, kv_half != 0, nch, 1, st);
+    OutMergeArgs m{};
+    m.W = wo; m.bias = bo; m.resid = resid; m.out = y; m.part_o = part; m.part_ml = part_ml; m.N = H * D;
+    if (e == hipSuccess) e = w_half ? launch_outproj_merge<_Float16, D>(m, nch, st) : launch_outproj_merge<float, D>(m, nch, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(part);
+    hipFree(part_ml);
     HIPRET(e);
     HIPRET(e2);
     return ER_OK;

@@ -27,13 +27,14 @@ struct AttnDecArgs {
     const int* pos;        // device, per row: index of the newest key (len = pos+1); or
     int fixed_len;         // >0: use this length for every row instead of pos
     const int* len_dev;    // optional per-row lengths (overrides pos when non-null)
-    float* part;           // [B][H][S][D+2] = {m, l, o[0..D)}
+    float* part;           // [B][H][S][D+2] = {m, l, o[0..D)}   (version 3: [B][H][NCH][D], o rows only)
+    float* part_ml;        // version 3: [B][H][NCH][2] = {m, l}
     float* out;            // combine: [B][hidden]
     int H, l_cap, S, hidden;   // S = number of chunks the grid covers = ceil(l_cap / chunk)
     int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS with half the steps)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
-    int grid_hs;           // partial kernel v2: 1 = grid (H, S, B): heads fastest, so the chunks beyond the current length (which exit at once) are dispatched LAST
+    int grid_hs;           // partial kernels: 1 = grid (H, S, B): heads fastest, so the chunks beyond the current length (which exit at once) are dispatched LAST
 };
 
 __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
@@ -74,7 +75,10 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_kernel(AttnDecArgs a) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & (LPK - 1), g = lane / LPK;
-    const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // heads fastest (grid_hs): workgroup id = h + H*s lands on XCD h % 8, so every XCD gets the same number of ACTIVE chunks.
+    // With chunks fastest and S a multiple of 8, chunk s always lands on XCD s % 8: at 33 active chunks XCD 0 works on 5
+    // chunks per head while the others hold 4 - the 137 -> 167 us jump of the batch-32 sweep between L = 3926 and 4176.
+    const int s = a.grid_hs ? blockIdx.y : blockIdx.x, h = a.grid_hs ? blockIdx.x : blockIdx.y, b = blockIdx.z;
     const int len = attn_len(a, b);
     const int k0 = s * CHUNK;
     if (k0 >= len) return;                    // inactive chunk: the merge only visits ceil(len/CHUNK) partials
@@ -417,6 +421,164 @@ __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
     if (half == 0 && c < D) a.out[(long long)b * a.hidden + h * D + c] = (o_run + half1[c]) / l_run;
 }
 
+// ---- version 3 (ER_DECODE_V=3, single row): BALANCED chunks + 16-byte aligned partials for the fused merge/out_proj kernel.
+//
+// v2 cuts the keys into fixed 128-key chunks, so the number of workgroups per head grows with the context and the kernel's
+// time is set by the CUs that happen to hold one workgroup more than the others (the 8.4 -> 10.3 -> 11.9 us staircase of
+// profiles/r02_bench.json).  Here the grid is ALWAYS (H, NCH): every head is cut into NCH equal chunks of ceil(len / NCH)
+// keys and one NW-wave workgroup takes a whole chunk (up to STEPS * NW * KPW keys), so with H * NCH = 256 every CU holds
+// exactly one workgroup at every context length and the merge always sees NCH partials per head.  The wave-step that holds
+// key group i*NW + w is step-major, so the number of active steps is uniform over the workgroup and is dispatched OUTSIDE the
+// unrolled load block (a per-load condition would make hipcc branch around - and wait for - every load).
+// Partials: o rows [B][H][NCH][D] (16-byte aligned float4 columns) and {m, l} pairs [B][H][NCH][2].
+template <typename KT, int D, int NS, int NW>
+__device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, const KT* vb, const float* qp, int k0, int k1,
+                                           float* ored, float* wm, float* wl, float* po, float* pml) {
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
+    constexpr int NV = D / (EPL * LPK);
+    constexpr int KPW = 64 / LPK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = lane & (LPK - 1), g = lane / LPK;
+    float qv[NV][EPL];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+        }
+    f32x4 kreg[NS][NV], vreg[NS][NV];
+    bool valid[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int kk = k0 + (i * NW + wid) * KPW + g;
+        valid[i] = kk < k1;
+        const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) kreg[i][j] = __builtin_nontemporal_load(kr + j * LPK + p);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int kk = k0 + (i * NW + wid) * KPW + g;
+        const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) vreg[i][j] = __builtin_nontemporal_load(vr + j * LPK + p);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float sc[NS];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float kf[EPL];
+            kv_unpack<KT>(kreg[i][j], kf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
+        }
+#pragma unroll
+        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
+        mloc = fmaxf(mloc, sc[i]);
+    }
+    const float m = wave_max(mloc);           // -inf when the wave holds no valid key
+    float pw[NS];
+    float lloc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        pw[i] = valid[i] ? expf(sc[i] - m) : 0.f;
+        if (p == 0) lloc += pw[i];
+    }
+    const float l = wave_sum(lloc);
+    float o[NV][EPL];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float vf[EPL];
+            kv_unpack<KT>(vreg[i][j], vf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
+        }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            o[j][e] += row_ror<8>(o[j][e]);
+            if (LPK == 4) o[j][e] += row_ror<4>(o[j][e]);
+        }
+    if ((lane & 15) < LPK) {
+        float* dst = ored + (wid * 4 + (lane >> 4)) * D;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dst[(j * LPK + p) * EPL + e] = o[j][e];
+    }
+    if (lane == 0) { wm[wid] = m; wl[wid] = l; }
+    __syncthreads();
+    if (tid < D) {
+        float M = wm[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) M = fmaxf(M, wm[k]);    // finite: the chunk holds at least one key
+        float ov = 0.f, lv = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const float w = (wm[k] == -INFINITY) ? 0.f : expf(wm[k] - M);
+            const float* src = ored + k * 4 * D + tid;
+            ov = fmaf((src[0] + src[D]) + (src[2 * D] + src[3 * D]), w, ov);
+            lv = fmaf(wl[k], w, lv);
+        }
+        po[tid] = ov;
+        if (tid == 0) { pml[0] = M; pml[1] = lv; }
+    }
+}
+
+template <typename KT, int D, int STEPS, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(AttnDecArgs a) {
+    constexpr int KPW = 64 / KVec<KT>::LPK;
+    __shared__ __attribute__((aligned(16))) float ored[NW * 4 * D];
+    __shared__ float wm[NW], wl[NW];
+    const int h = blockIdx.x, c = blockIdx.y, b = blockIdx.z, nch = gridDim.y;
+    const int len = attn_len(a, b);
+    const int clen = (len + nch - 1) / nch;                 // <= STEPS * NW * KPW (the launcher checks l_cap)
+    const int k0 = c * clen, k1 = min(len, k0 + clen);
+    float* po = a.part + (((long long)b * a.H + h) * nch + c) * D;
+    float* pml = a.part_ml + (((long long)b * a.H + h) * nch + c) * 2;
+    if (k0 >= k1) {                                        // empty chunk (len < nch): a partial the merge weighs with exp(-inf) = 0
+        if (threadIdx.x < D) po[threadIdx.x] = 0.f;
+        if (threadIdx.x == 0) { pml[0] = -INFINITY; pml[1] = 0.f; }
+        return;
+    }
+    const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
+    const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
+    const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
+    const float* qp = a.q + (long long)b * a.hidden + h * D;
+    const int nsteps = (k1 - k0 + NW * KPW - 1) / (NW * KPW);      // workgroup-uniform
+    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    else attn3_body<KT, D, 1, NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+}
+
+constexpr int ATTN3_NW = 16;                   // waves per workgroup of the balanced kernel
+constexpr int ATTN3_CAP = 512;                 // keys per workgroup: fp32 4 steps x 16 waves x 8, fp16 2 steps x 16 waves x 16
+inline int attn3_num_chunks(int heads) { return heads >= 16 ? 16 : 32; }   // H * NCH = 256 workgroups for the 16-head decoder
+inline bool attn3_fits(int l_cap, int heads) { return l_cap <= attn3_num_chunks(heads) * ATTN3_CAP; }
+
+template <int D>
+inline hipError_t launch_attn_partial3_d(const AttnDecArgs& a, bool kv_half, int nch, int B, hipStream_t st) {
+    const dim3 grid(a.H, nch, B), blk(64 * ATTN3_NW);
+    if (!kv_half) hipLaunchKernelGGL((attn_decode3_kernel<float, D, 4, ATTN3_NW>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((attn_decode3_kernel<_Float16, D, 2, ATTN3_NW>), grid, blk, 0, st, a);
+    return hipGetLastError();
+}
+
 constexpr int ATTN_STEPS_DEFAULT = 4;          // fp32 KV: 128 keys per workgroup
 inline int attn_chunk(int steps, bool /*kv_half*/) { return 32 * steps; }   // fp16 KV: 64 keys/step x steps/2
 inline int attn_num_chunks(int l_cap, int chunk) { return (l_cap + chunk - 1) / chunk; }
@@ -424,7 +586,7 @@ inline int attn_num_chunks(int l_cap, int chunk) { return (l_cap + chunk - 1) / 
 // `steps` is the fp32 step count (chunk = 32*steps keys); fp16 KV uses half as many steps for the same chunk.
 template <int D>
 inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv_half, int B, hipStream_t st, int version = 2) {
-    const dim3 grid(a.S, a.H, B), blk(ER_WG);
+    const dim3 grid = a.grid_hs ? dim3(a.H, a.S, B) : dim3(a.S, a.H, B), blk(ER_WG);
     if (version == 2) {
         const dim3 grid = a.grid_hs ? dim3(a.H, a.S, B) : dim3(a.S, a.H, B);
         if (!kv_half) {

@@ -120,13 +120,18 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
     constexpr int TPB = 64 * NW;
     constexpr int EPL = WTraits<WT>::EPL, XV = EPL / 4, SL = 1536, J = SL / (64 * EPL);
     constexpr int K = KS * SL;
-    constexpr int PT = K / TPB;    // elements per thread in the prologue
-    static_assert(K % TPB == 0 && (KS == 1 || NW == ER_NWAVES), "prologue / split-K shape");
+    // the prologue (LayerNorm / embedding) always runs on at most 4 waves with the 256-thread element mapping and reduction
+    // order, so a 6-wave workgroup (768 qkv workgroups = 3 per CU) produces bit-identical inputs; waves 4 and 5 only take
+    // part in its barriers
+    constexpr int PW = NW > 4 ? 4 : NW, PTPB = 64 * PW;
+    constexpr int PT = K / PTPB;   // elements per thread in the prologue
+    static_assert(K % PTPB == 0 && (KS == 1 || NW == ER_NWAVES), "prologue / split-K shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;              // [NB][K]
     float* red = smem + NB * K;    // 64 floats
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int slice = (KS == 1) ? 0 : wid;                 // K-slice this wave reduces
+    const bool pro = (NW <= 4) || wid < PW;                // wave-uniform: this wave takes part in the prologue arithmetic
     const int row0 = (KS == 1) ? (blockIdx.x * NW + wid) * RW : blockIdx.x * RW;
 
     // ---------------- loads, in the order their consumers run.  Vector loads complete in issue order (vmcnt), so the
@@ -136,23 +141,23 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
     float v[NB][PT];
     float v2[PRO == PRO_EMBED ? NB : 1][PT];   // PRO_EMBED: position rows (added after the weight loads are out)
     float lw[PT], lb[PT];
-    if (PRO == PRO_EMBED) {
+    if (PRO == PRO_EMBED && pro) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float* e = a.embd + (long long)a.tok[b] * K;
             const float* p = a.posemb + (long long)a.pos[b] * K;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) { v[b][i] = e[tid + i * TPB]; v2[b][i] = p[tid + i * TPB]; }
+            for (int i = 0; i < PT; ++i) { v[b][i] = e[tid + i * PTPB]; v2[b][i] = p[tid + i * PTPB]; }
         }
-    } else if (PRO == PRO_LN) {
+    } else if (PRO == PRO_LN && pro) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float* x = a.xin + (long long)b * K;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) v[b][i] = x[tid + i * TPB];
+            for (int i = 0; i < PT; ++i) v[b][i] = x[tid + i * PTPB];
         }
 #pragma unroll
-        for (int i = 0; i < PT; ++i) { lw[i] = a.ln_w[tid + i * TPB]; lb[i] = a.ln_b[tid + i * TPB]; }
+        for (int i = 0; i < PT; ++i) { lw[i] = a.ln_w[tid + i * PTPB]; lb[i] = a.ln_b[tid + i * PTPB]; }
     }
     // epilogue operands of the (row, batch) pairs this thread will finish
     EpiPre pre[RW][NB];
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
     // dot-product register layout below: no staging, no barrier)
 #pragma unroll
     for (int b = 0; b < NB && PRO != PRO_NONE; ++b) {
-        if (PRO == PRO_EMBED) {
+        if (PRO == PRO_EMBED && pro) {
 #pragma unroll
             for (int i = 0; i < PT; ++i) v[b][i] += v2[b][i];
         }
@@ -187,21 +192,25 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
             // each reduction has its own LDS slot, so it costs one barrier instead of two (same summation order as block_sum)
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) s += v[b][i];
-            const float mean = block_sum_slot<NW>(s, red + 8 * b) / (float)K;
+            for (int i = 0; i < PT; ++i) s += pro ? v[b][i] : 0.f;
+            const float mean = block_sum_slot<PW>(s, red + 8 * b, pro) / (float)K;
             float s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) { const float d = v[b][i] - mean; s2 = fmaf(d, d, s2); }
-            const float var = block_sum_slot<NW>(s2, red + 8 * b + 4) / (float)K;
+            for (int i = 0; i < PT; ++i) { const float d = (pro ? v[b][i] : 0.f) - mean; s2 = fmaf(d, d, s2); }
+            const float var = block_sum_slot<PW>(s2, red + 8 * b + 4, pro) / (float)K;
             const float rstd = 1.0f / sqrtf(var + a.eps);
+            if (pro) {
 #pragma unroll
-            for (int i = 0; i < PT; ++i) v[b][i] = (v[b][i] - mean) * rstd * lw[i] + lb[i];
+                for (int i = 0; i < PT; ++i) v[b][i] = (v[b][i] - mean) * rstd * lw[i] + lb[i];
+            }
         }
+        if (pro) {
 #pragma unroll
-        for (int i = 0; i < PT; ++i) xs[b * K + tid + i * TPB] = v[b][i];
-        if (PRO != PRO_NONE && a.hout != nullptr && blockIdx.x == 0) {
+            for (int i = 0; i < PT; ++i) xs[b * K + tid + i * PTPB] = v[b][i];
+            if (PRO != PRO_NONE && a.hout != nullptr && blockIdx.x == 0) {
 #pragma unroll
-            for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * TPB] = v[b][i];
+                for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * PTPB] = v[b][i];
+            }
         }
     }
     if (PRO != PRO_NONE) __syncthreads();

@@ -38,6 +38,20 @@ def attn_decode(q, k_cache, v_cache, lens, steps=4):
     return out
 
 
+def attn_outproj3(q, k_cache, v_cache, length, wo, bo, resid):
+    """Version-3 single-row path: y = Wo . attention(q, K[:length], V[:length]) + bo + resid.
+    q [1536] fp32; caches [16,Lcap,96] fp32 or fp16; wo [1536,1536] fp32 or fp16."""
+    lib = native.load_library()
+    H, Lcap, D = k_cache.shape
+    assert (H, D) == (16, 96)
+    y = torch.empty((H * D,), dtype=torch.float32, device=q.device)
+    native.check(lib.er_k_attn_outproj3(native.ptr(q), native.ptr(k_cache), native.ptr(v_cache), int(length), native.ptr(wo),
+                                        native.ptr(bo), native.ptr(resid), native.ptr(y), Lcap,
+                                        int(k_cache.dtype == torch.float16), int(wo.dtype == torch.float16), _st()),
+                 "er_k_attn_outproj3")
+    return y
+
+
 def gemm(a, b, bias=None, resid=None, b_is_kn=False, relu=False, div=0.0, m=None, n=None, k=None):
     """C = A.op(B) with row strides taken from the (2-D, row-contiguous) tensors."""
     lib = native.load_library()

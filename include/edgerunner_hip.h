@@ -232,6 +232,12 @@ int er_k_gemv(const float* w_dev, const float* bias_dev, const float* x_dev, con
 int er_k_attn_decode(const float* q_dev, const void* k_dev, const void* v_dev, const int32_t* len_host,
                      float* out_dev, int batch, int heads, int head_dim, int l_cap, int steps, int kv_half,
                      void* stream);
+/* Version 3 of the single-row decode attention (env ER_DECODE_V=3), one row, 16 heads of 96:
+ * y[1536] = Wo . softmax(q K^T / sqrt(D)) V + bo + resid over a [16,Lcap,96] cache holding len keys (Lcap <= 8192):
+ * balanced chunks (16 per head) + the partial merge fused into the out_proj GEMV; w_half: Wo is fp16 */
+int er_k_attn_outproj3(const float* q_dev, const void* k_dev, const void* v_dev, int len, const void* wo_dev,
+                       const float* bo_dev, const float* resid_dev, float* y_dev, int l_cap, int kv_half, int w_half,
+                       void* stream);
 /* C[M,N] = A[M,K] op(B) (+bias)(relu)(+resid); b_is_kn=0: B is [N,K] (Linear weight), 1: B is [K,N] */
 int er_k_gemm(const float* a_dev, const float* b_dev, const float* bias_dev, const float* resid_dev,
               float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int b_is_kn, int relu,

@@ -18,7 +18,7 @@ from edgerunner_amd.options import config_defaults  # noqa: E402
 T = int(os.environ.get("TUNE_TOKENS", "1000"))
 CONFIGS = [dict()] + [dict(c) for c in json.loads(os.environ.get("TUNE_CONFIGS", "[]"))]
 KNOBS = ["ER_RW_QKV", "ER_RW_FC1", "ER_RW_FC2", "ER_RW_OUT", "ER_ATTN_STEPS", "ER_NO_GRAPH", "ER_PROF_LAYERS", "ER_ATTN_V", "ER_COMBINE_V",
-         "ER_NW_QKV", "ER_NW_OUT", "ER_PREFILL_ATTN", "ER_DEBUG_KV_FLAT", "ER_ATTN_GRID_HS", "ER_PREFILL_GEMM"]
+         "ER_NW_QKV", "ER_NW_OUT", "ER_PREFILL_ATTN", "ER_DEBUG_KV_FLAT", "ER_ATTN_GRID_HS", "ER_PREFILL_GEMM", "ER_DECODE_V"]
 PRECISION = os.environ.get("TUNE_PRECISION", "fp32")
 
 
@@ -27,6 +27,10 @@ def main():
     t0 = time.time()
     sd = W.make_state_dict(opt, 0, "perturbed")
     print(f"weights in {time.time() - t0:.1f}s", flush=True)
+    run(opt, sd, CONFIGS, PRECISION, T)
+
+
+def run(opt, sd, CONFIGS, PRECISION, T):
     pc = W.synthetic_point_cloud(0, 4096).to("cuda:0")
     ref = None
     for cfg in CONFIGS:
@@ -54,10 +58,12 @@ def main():
                           "encode_prefill_ms": round(pre_ms, 1),
                           "sweep_us_per_token": round(per_tok, 1),
                           "kinds_us": {k: round(v["avg_us"], 2) for k, v in prof.items()},
-                          "kinds_GBps": {k: round(v["bytes"] / v["avg_us"] / 1e3, 0) for k, v in prof.items()}}), flush=True)
+                          "kinds_GBps": {k: round(v["bytes"] / max(v["avg_us"], 1e-9) / 1e3, 0) for k, v in prof.items()}}), flush=True)
         lmm.mesh_decoder.close()
         del lmm
         torch.cuda.empty_cache()
+    for k in KNOBS:
+        os.environ.pop(k, None)
 
 
 if __name__ == "__main__":

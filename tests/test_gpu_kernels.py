@@ -169,6 +169,32 @@ def test_attn_decode_fp16_cache(D, lens, steps):
         close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"fp16-KV attn row {b} len {n}")
 
 
+@pytest.mark.parametrize("length,lcap,kv16,w16", [(1, 64, False, False), (17, 64, False, False), (129, 160, False, False),
+                                                  (2051, 6080, False, False), (4097, 6080, False, False),
+                                                  (6049, 6080, False, False), (8192, 8192, False, False),
+                                                  (15, 64, True, True), (2063, 6080, True, True), (8191, 8192, True, False)])
+def test_attn_outproj3_balanced_chunks_fused_merge(length, lcap, kv16, w16):
+    """Version 3 of the single-row decode attention (ER_DECODE_V=3): 16 balanced chunks per head, the partial merge fused
+    into the out_proj GEMV.  y = Wo . softmax(q K^T / sqrt(D)) V + bo + resid vs float64 torch; the unused cache tail is
+    NaN-poisoned, chunks may be empty (length < 16) or ragged."""
+    from edgerunner_amd import kernels as K
+    H, D = 16, 96
+    q = rnd(H * D, seed=60)
+    kc, vc = rnd(H, lcap, D, seed=61), rnd(H, lcap, D, seed=62)
+    wo, bo, resid = rnd(H * D, H * D, seed=63) * 0.05, rnd(H * D, seed=64), rnd(H * D, seed=65)
+    if kv16:
+        kc, vc = kc.half(), vc.half()
+    if w16:
+        wo = wo.half()
+    kc[:, length:] = float("nan")
+    vc[:, length:] = float("nan")
+    y = K.attn_outproj3(q, kc, vc, length, wo, bo, resid)
+    w = torch.softmax(q.view(H, 1, D).double() @ kc[:, :length].double().transpose(1, 2) / math.sqrt(D), dim=-1)
+    o = (w @ vc[:, :length].double()).reshape(H * D)
+    ref = wo.double() @ o + bo.double() + resid.double()
+    close(y, ref, 2e-5, 1e-5, f"attn+out_proj v3 len {length}")
+
+
 # ------------------------------------------------------------------ MFMA GEMM (prefill / encoder)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (2050, 1536, 1536), (2050, 6144, 1536), (300, 64, 1024),
                                    (2048, 1024, 64), (77, 200, 96)])

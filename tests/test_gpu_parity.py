@@ -23,7 +23,8 @@ def make_lmm(num_layers=2, seed=0, style="perturbed", precision="fp32", **kw):
     from edgerunner_amd import weights as W
     from edgerunner_amd.models import LMM
     from edgerunner_amd.options import config_defaults
-    key = (num_layers, seed, style, precision, tuple(sorted(kw.items())), os.environ.get("ER_NO_GRAPH", ""))
+    key = (num_layers, seed, style, precision, tuple(sorted(kw.items())),
+           tuple(os.environ.get(k, "") for k in ("ER_NO_GRAPH", "ER_DECODE_V", "ER_NW_QKV")))
     if key not in _CACHE:
         opt = dataclasses.replace(config_defaults["ArAE"], num_layers=num_layers, generate_mode="greedy", **kw)
         m = LMM(opt, DEV, precision=precision)
@@ -225,6 +226,39 @@ def test_graph_replay_equals_eager(gold_small, monkeypatch):
     lmm = make_lmm()          # separate context created with graphs disabled
     _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
     assert_ids(toks[0], gold_small["ids_min96"][0], "eager launches")
+
+
+# ------------------------------------------------------------------ decode version 3 (balanced attention chunks, merge fused into out_proj)
+@pytest.mark.parametrize("knobs", [{"ER_DECODE_V": "3"}, {"ER_NW_QKV": "6"}, {"ER_DECODE_V": "3", "ER_NW_QKV": "6"}])
+def test_decode_v3_and_6wave_qkv_small(gold_small, monkeypatch, knobs):
+    """The alternative single-row decode kernels behind ER_DECODE_V=3 / ER_NW_QKV=6: golden ids, teacher-forced logits."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    lmm = make_lmm()          # separate context: the knobs are read at er_create
+    _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
+    assert_ids(toks[0], gold_small["ids_min96"][0], f"{knobs}: EOS suppressed until 96")
+    _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=256)
+    assert_ids(toks[0], gold_small["ids_natural"][0], f"{knobs}: natural")
+    want = gold_small["logits_min96"][:, 0]
+    got = teacher_forced_logits(lmm, cloud(0), 1000, gold_small["ids_min96"][0], set(range(96)))
+    err = max(np.abs(got[t] - want[t]).max() for t in range(96))
+    print(f"{knobs}: teacher-forced max|dlogit| over 96 steps: {err:.3e}")
+    assert err < LOGIT_TOL
+
+
+def test_decode_v3_fast_mode_matches_v2(monkeypatch):
+    """fp16 storage: the version-3 kernels against the default ones on the same context (ids equal, logits to round-off)."""
+    base = make_lmm(precision="fp16")
+    _, t2 = base.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
+    l2 = teacher_forced_logits(base, cloud(2), 1000, t2[0], set(range(0, 64, 7)))
+    monkeypatch.setenv("ER_DECODE_V", "3")
+    v3 = make_lmm(precision="fp16")
+    _, t3 = v3.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
+    assert_ids(t3[0], t2[0], "fp16 storage, version 3 vs version 2")
+    l3 = teacher_forced_logits(v3, cloud(2), 1000, t2[0], set(range(0, 64, 7)))
+    err = max(np.abs(l3[t] - l2[t]).max() for t in l2)
+    print(f"fp16 v3 vs v2 max|dlogit|: {err:.3e}")
+    assert err < 1e-4
 
 
 # ------------------------------------------------------------------ host callable path, sample mode
@@ -544,11 +578,15 @@ def test_config2_shape_sample_mode_distributions(gold_batch):
 
 
 # ------------------------------------------------------------------ BASELINE configs[1]: full size, T = 4000
-def test_full_size_greedy_T4000_bit_exact(gold_full, manifest):
+@pytest.mark.parametrize("decode_v", ["2", "3"])
+def test_full_size_greedy_T4000_bit_exact(gold_full, manifest, monkeypatch, decode_v):
     """ArAE 24 layers, cloud 0 (4096 pts), greedy, test_num_face=1000, 4000 new tokens with EOS
-    suppressed until T: ids must equal the reference CPU-eager run bit for bit."""
+    suppressed until T: ids must equal the reference CPU-eager run bit for bit.  Both single-row decode versions
+    (ER_DECODE_V: 2 = fixed 128-key chunks + merge kernel, 3 = balanced chunks + merge fused into out_proj)."""
     from edgerunner_amd.grammar import GrammarState
     from edgerunner_amd import native
+    if decode_v != "2":
+        monkeypatch.setenv("ER_DECODE_V", decode_v)
     lmm = make_lmm(num_layers=24)
     want = gold_full["ids"][0]
     T = len(want)
