@@ -30,15 +30,14 @@ def main():
         print(f"=== {sec} (+{time.time() - t0:.0f}s)", flush=True)
         try:
             if sec == "tune32":
-                tune_decode.run(opt, sd, [{}, v3, {"ER_NW_QKV": 6}, {**v3, "ER_NW_QKV": 6}], "fp32", 1000)
+                tune_decode.run(opt, sd, [{}, v3, {**v3, "ER_NW_QKV": 6}], "fp32", 1000)
             elif sec == "tune16":
-                tune_decode.run(opt, sd, [{}, v3, {**v3, "ER_NW_QKV": 6}], "fp16", 1000)
+                tune_decode.run(opt, sd, [{}, {**v3, "ER_NW_QKV": 6}], "fp16", 1000)
             elif sec == "sweep1":
-                ctx = [2060, 2176, 2426, 2926, 3426, 3926, 4050, 4100, 4176, 4676, 5176, 5676, 6040]
+                ctx = [2060, 2426, 2926, 3426, 3926, 4050, 4176, 4676, 5176, 5676, 6040]
                 attn_sweep.run(opt, sd, [{}, v3], "fp32", 1, 4000, ctx)
-                attn_sweep.run(opt, sd, [{}, v3], "fp16", 1, 4000, [2176, 4050, 6040])
             elif sec == "sweep32":
-                ctx = [2176, 3176, 3926, 4050, 4176, 4426, 5176, 5926]
+                ctx = [2176, 3176, 3926, 4176, 4426, 5176, 5926]
                 attn_sweep.run(opt, sd, [{}, {"ER_ATTN_GRID_HS": 0}], "fp16", 32, 4000, ctx)
         except Exception:
             traceback.print_exc()

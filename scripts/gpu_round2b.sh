@@ -10,12 +10,12 @@ for SEC in "$@"; do
   echo "=================== $SEC"
   case "$SEC" in
     unit)
-      timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider --timeout 300 -k "outproj3 or attn_decode or gemv" 2>&1 | filt | tail -15 | tee gpurun_out/r2b_unit.log ;;
+      timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider --timeout 300 -k "${UNIT_K:-outproj3}" 2>&1 | filt | tail -15 | tee gpurun_out/r2b_unit.log ;;
     explore)
       timeout 900 python scripts/explore_r2b.py ${EXPLORE_SECTIONS:-tune32 tune16 sweep1 sweep32} 2>&1 | filt | tee gpurun_out/r2b_explore.log ;;
     parity)
       timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -p no:cacheprovider --timeout 600 \
-        -k "decode_v3 or full_size or batch_rows_bit_identical or teacher_forced_logits_24 or greedy_min_new" 2>&1 | filt | tail -40 | tee gpurun_out/r2b_parity.log ;;
+        -k "${PARITY_K:-decode_v3 or (full_size and 3)}" 2>&1 | filt | tail -40 | tee gpurun_out/r2b_parity.log ;;
     *) echo "unknown section $SEC" ;;
   esac
 done
