@@ -120,7 +120,8 @@ struct er_ctx {
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_grid_hs = 1;     // attention partial kernel (v2) dispatched heads-fastest: chunks beyond the current length exit last (ER_ATTN_GRID_HS=0: chunks fastest)
     bool out_valu = false;    // ER_OUT_VALU=1: batched out_proj on the VALU kernel (round-1 choice)
-    int attn_v_batched = 1;   // attention partial kernel version at B > 4 (env ER_ATTN_V_BATCHED)
+    int attn_v_batched = 1;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 1 / 2 = split kernels + merge, 3 = one streaming workgroup per (row, head), no merge
+    bool stream_attn = false; // batched && attn_v_batched == 3 && D == 96
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     int decode_v = 2;         // ER_DECODE_V=3: balanced-chunk attention + merge fused into out_proj (single row, D = 96, 16 heads, Lcap <= 8192)
     bool v3 = false;          // decode_v == 3 and the reserved cache qualifies
@@ -239,7 +240,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 1) == 0 ? 0 : 1;
-    c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 1) == 2 ? 2 : 1;
+    c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 1);
+    if (c->attn_v_batched != 2 && c->attn_v_batched != 3) c->attn_v_batched = 1;
     c->out_valu = env_int("ER_OUT_VALU", 0) == 1;
     c->decode_v = env_int("ER_DECODE_V", 2) == 3 ? 3 : 2;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
@@ -589,6 +591,7 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     const char* bv = getenv("ER_BATCHED_VALU");
     c->batched_valu = bv && bv[0] == '1';
     if (c->batched && !c->batched_valu) ERCHK(make_tiled_weights(c));
+    c->stream_attn = c->batched && c->attn_v_batched == 3 && D == 96;
     c->v3 = c->decode_v == 3 && batch == 1 && !c->batched && D == 96 && H == 16 && hid == 1536 && attn3_fits(Lcap, H);
     return ER_OK;
 }
@@ -760,10 +763,11 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
         // worth of work (B > 4) the leaner v1 (66-74 VGPRs, 6-7 waves per SIMD) streams faster: 570 vs 636 us at B = 32, L = 18050
         case 1:
             if (c->v3) return launch_attn_partial3_d<96>(attn_args(c, layer), HALF, c->nch3, B, st);
+            if (c->stream_attn) return launch_attn_stream_d<96>(attn_args(c, layer), HALF, B, st);
             return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st,
                                        (c->batched && c->attn_v_batched == 1) ? 1 : c->attn_v);
         case 2:
-            if (c->v3) return hipSuccess;      // the merge runs inside the out_proj kernel
+            if (c->v3 || c->stream_attn) return hipSuccess;      // the merge runs inside the out_proj kernel / there are no partials
             return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
@@ -1303,7 +1307,7 @@ static int profile_impl(er_ctx* c, int repeats, int use_graph, float* avg_us, do
     }
     for (int kind = 0; kind < ER_NUM_KERNEL_KINDS; ++kind) {
         const bool per_layer = kind <= 5;
-        if (c->v3 && kind == 2) { avg_us[kind] = 0.f; continue; }
+        if ((c->v3 || c->stream_attn) && kind == 2) { avg_us[kind] = 0.f; continue; }
         // warm-up + timed sweeps
         hipGraphExec_t gexec = nullptr;
         if (use_graph && per_layer) {     // the nl launches of this kind as one replayable graph (what the generation loop replays)
@@ -1433,8 +1437,14 @@ extern "C" int er_k_attn_decode(const float* q, const void* k, const void* v, co
     a.q = q; a.kcache = k; a.vcache = v; a.len_dev = len_dev; a.part = part; a.out = out;
     a.H = heads; a.l_cap = l_cap; a.S = S; a.hidden = heads * head_dim; a.chunk = attn_chunk(steps, kv_half != 0);
     a.kv_bstride = (long long)heads * l_cap * head_dim; a.sqrt_d = sqrtf((float)head_dim);
-    hipError_t e = launch_attn_partial(a, head_dim, steps, kv_half != 0, B, st, env_version("ER_ATTN_V"));
-    if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st, env_version("ER_COMBINE_V"));
+    const char* sv = getenv("ER_ATTN_V_BATCHED");
+    hipError_t e;
+    if (sv && sv[0] == '3' && head_dim == 96) {       // the streaming kernel of the batched decode step (no partials)
+        e = launch_attn_stream_d<96>(a, kv_half != 0, B, st);
+    } else {
+        e = launch_attn_partial(a, head_dim, steps, kv_half != 0, B, st, env_version("ER_ATTN_V"));
+        if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st, env_version("ER_COMBINE_V"));
+    }
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(len_dev);
     hipFree(part);

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
 // Partials: o rows [B][H][NCH][D] (16-byte aligned float4 columns) and {m, l} pairs [B][H][NCH][2].
 template <typename KT, int D, int NS, int NW>
 __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, const KT* vb, const float* qp, int k0, int k1,
-                                           float* ored, float* wm, float* wl, float* po, float* pml) {
+                                           float* ored, float* wm, float* wl, float* gsum, float* gl, float* po, float* pml) {
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
     constexpr int NV = D / (EPL * LPK);
     constexpr int KPW = 64 / LPK;
@@ -522,18 +522,31 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
     }
     if (lane == 0) { wm[wid] = m; wl[wid] = l; }
     __syncthreads();
-    if (tid < D) {
-        float M = wm[0];
+    // two-level merge of the NW wave partials: NW/2 groups of D threads weigh two waves each (one expf per wave instead of
+    // NW per thread), then D threads add the NW/2 group sums - 96 threads walking all 16 waves cost ~0.5 us of tail
+    constexpr int NG = NW / 2;
+    float M = wm[0];
 #pragma unroll
-        for (int k = 1; k < NW; ++k) M = fmaxf(M, wm[k]);    // finite: the chunk holds at least one key
+    for (int k = 1; k < NW; ++k) M = fmaxf(M, wm[k]);        // finite: the chunk holds at least one key
+    const int grp = tid / D, d = tid - grp * D;
+    if (grp < NG) {
         float ov = 0.f, lv = 0.f;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = 2 * grp + kk;
             const float w = (wm[k] == -INFINITY) ? 0.f : expf(wm[k] - M);
-            const float* src = ored + k * 4 * D + tid;
+            const float* src = ored + k * 4 * D + d;
             ov = fmaf((src[0] + src[D]) + (src[2 * D] + src[3 * D]), w, ov);
             lv = fmaf(wl[k], w, lv);
         }
+        gsum[grp * D + d] = ov;
+        if (d == 0) gl[grp] = lv;
+    }
+    __syncthreads();
+    if (tid < D) {
+        float ov = 0.f, lv = 0.f;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) { ov += gsum[q * D + tid]; lv += gl[q]; }
         po[tid] = ov;
         if (tid == 0) { pml[0] = M; pml[1] = lv; }
     }
@@ -542,8 +555,10 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
 template <typename KT, int D, int STEPS, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(AttnDecArgs a) {
     constexpr int KPW = 64 / KVec<KT>::LPK;
+    static_assert(NW % 2 == 0 && (NW / 2) * D <= 64 * NW, "two-level merge: NW/2 groups of D threads");
     __shared__ __attribute__((aligned(16))) float ored[NW * 4 * D];
-    __shared__ float wm[NW], wl[NW];
+    __shared__ float gsum[(NW / 2) * D];
+    __shared__ float wm[NW], wl[NW], gl[NW / 2];
     const int h = blockIdx.x, c = blockIdx.y, b = blockIdx.z, nch = gridDim.y;
     const int len = attn_len(a, b);
     const int clen = (len + nch - 1) / nch;                 // <= STEPS * NW * KPW (the launcher checks l_cap)
@@ -560,10 +575,10 @@ __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(AttnDecArgs a) {
     const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
     const float* qp = a.q + (long long)b * a.hidden + h * D;
     const int nsteps = (k1 - k0 + NW * KPW - 1) / (NW * KPW);      // workgroup-uniform
-    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else attn3_body<KT, D, 1, NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
+    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
+    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
+    else attn3_body<KT, D, 1, NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
 }
 
 constexpr int ATTN3_NW = 16;                   // waves per workgroup of the balanced kernel
@@ -576,6 +591,175 @@ inline hipError_t launch_attn_partial3_d(const AttnDecArgs& a, bool kv_half, int
     const dim3 grid(a.H, nch, B), blk(64 * ATTN3_NW);
     if (!kv_half) hipLaunchKernelGGL((attn_decode3_kernel<float, D, 4, ATTN3_NW>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((attn_decode3_kernel<_Float16, D, 2, ATTN3_NW>), grid, blk, 0, st, a);
+    return hipGetLastError();
+}
+
+// ---- streaming variant for batches (ER_ATTN_V_BATCHED=3): ONE workgroup per (row, head) walks the whole key range.
+//
+// With B*H >= 256 (row, head) pairs there is nothing to gain from cutting the keys into chunks: the split kernels above
+// launch B*H*ceil(L/128) short-lived workgroups (24.5k at B = 32), each paying its own q load, load-wait-compute ramp,
+// barriers and partial write, plus a merge launch.  Here grid = (H, B) (heads fastest: XCD = h % 8), 4 waves; wave w owns
+// key groups (4*i + w) of every 4*STEPS*KPW-key tile and keeps its OWN running softmax {m, l-per-lane, o-per-lane} - no
+// workgroup barrier inside the loop - with two register tiles in flight (the loads of tile t+1 are issued before tile t is
+// reduced; loads are unconditional - past the end every lane re-reads the last key row - because a load under a condition
+// makes hipcc wait for everything at the join).  The lane groups of a wave share the wave's running maximum, so their o / l accumulators add
+// up without rescaling: one DPP + LDS reduction at the very end, the four waves merged like four partials, and the
+// normalised head output written straight to out[b][h*D..] - no partials, no merge kernel.
+template <typename KT, int D, int STEPS>
+struct AttnTile { f32x4 k[STEPS][D / (KVec<KT>::EPL * KVec<KT>::LPK)], v[STEPS][D / (KVec<KT>::EPL * KVec<KT>::LPK)]; };
+
+template <typename KT, int D, int STEPS>
+__device__ __forceinline__ void attn_stream_load(AttnTile<KT, D, STEPS>& t, const KT* kb, const KT* vb, int kbase, int len, int wid,
+                                                 int g, int p) {
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK), KPW = 64 / LPK;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int kk = min(kbase + (i * ER_NWAVES + wid) * KPW + g, len - 1);    // clamped: never reads the unused tail
+        const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)kk * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) t.k[i][j] = __builtin_nontemporal_load(kr + j * LPK + p);
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int kk = min(kbase + (i * ER_NWAVES + wid) * KPW + g, len - 1);
+        const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)kk * D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) t.v[i][j] = __builtin_nontemporal_load(vr + j * LPK + p);
+    }
+}
+
+template <typename KT, int D, int STEPS>
+__device__ __forceinline__ void attn_stream_reduce(const AttnTile<KT, D, STEPS>& t, const float (&qv)[D / (KVec<KT>::EPL * KVec<KT>::LPK)][KVec<KT>::EPL],
+                                                   int kbase, int len, int wid, int g, int p, float sqrt_d, float& m_run, float& l_lane,
+                                                   float (&o)[D / (KVec<KT>::EPL * KVec<KT>::LPK)][KVec<KT>::EPL]) {
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK), KPW = 64 / LPK;
+    float sc[STEPS];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float kf[EPL];
+            kv_unpack<KT>(t.k[i][j], kf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
+        }
+#pragma unroll
+        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        const bool valid = kbase + (i * ER_NWAVES + wid) * KPW + g < len;
+        sc[i] = valid ? acc / sqrt_d : -INFINITY;
+        mloc = fmaxf(mloc, sc[i]);
+    }
+    const float m_new = fmaxf(m_run, wave_max(mloc));
+    if (m_new == -INFINITY) return;                      // wave-uniform: this wave has not seen a valid key yet
+    const float alpha = expf(m_run - m_new);             // exp(-inf) = 0 on the first tile with keys
+    float pw[STEPS];
+    float ladd = 0.f;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        pw[i] = expf(sc[i] - m_new);                     // 0 for masked keys
+        ladd += pw[i];
+    }
+    l_lane = fmaf(l_lane, alpha, p == 0 ? ladd : 0.f);   // each key counted once (the LPK lanes of a key hold the same score)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[j][e] *= alpha;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float vf[EPL];
+            kv_unpack<KT>(t.v[i][j], vf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
+        }
+    m_run = m_new;
+}
+
+template <typename KT, int D, int STEPS>
+__global__ __launch_bounds__(ER_WG) void attn_stream_kernel(AttnDecArgs a) {
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
+    constexpr int NV = D / (EPL * LPK);
+    constexpr int KPW = 64 / LPK;
+    constexpr int TILE = ER_NWAVES * STEPS * KPW;        // keys per workgroup iteration
+    __shared__ __attribute__((aligned(16))) float ored[ER_NWAVES * 4 * D];
+    __shared__ float wm[ER_NWAVES], wl[ER_NWAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = lane & (LPK - 1), g = lane / LPK;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int len = attn_len(a, b);
+    const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
+    const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
+    const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
+    float qv[NV][EPL];
+    const float* qp = a.q + (long long)b * a.hidden + h * D;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+        }
+    float o[NV][EPL];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[j][e] = 0.f;
+    float m_run = -INFINITY, l_lane = 0.f;
+
+    const int nt = (len + TILE - 1) / TILE;               // >= 1
+    AttnTile<KT, D, STEPS> ta, tb;
+    attn_stream_load<KT, D, STEPS>(ta, kb, vb, 0, len, wid, g, p);
+    for (int t = 0; t < nt; t += 2) {
+        attn_stream_load<KT, D, STEPS>(tb, kb, vb, (t + 1) * TILE, len, wid, g, p);   // past the end: every lane re-reads row len-1 (one L1 line set)
+        __builtin_amdgcn_sched_barrier(0);
+        attn_stream_reduce<KT, D, STEPS>(ta, qv, t * TILE, len, wid, g, p, a.sqrt_d, m_run, l_lane, o);
+        __builtin_amdgcn_sched_barrier(0);
+        attn_stream_load<KT, D, STEPS>(ta, kb, vb, (t + 2) * TILE, len, wid, g, p);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) attn_stream_reduce<KT, D, STEPS>(tb, qv, (t + 1) * TILE, len, wid, g, p, a.sqrt_d, m_run, l_lane, o);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- the wave's lane groups share m_run: add their accumulators (rows of 16 lanes by DPP, the rest through LDS)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            o[j][e] += row_ror<8>(o[j][e]);
+            if (LPK == 4) o[j][e] += row_ror<4>(o[j][e]);
+        }
+    const float l = wave_sum(l_lane);
+    if ((lane & 15) < LPK) {
+        float* dst = ored + (wid * 4 + (lane >> 4)) * D;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dst[(j * LPK + p) * EPL + e] = o[j][e];
+    }
+    if (lane == 0) { wm[wid] = m_run; wl[wid] = l; }
+    __syncthreads();
+    if (tid < D) {
+        const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));   // finite: len >= 1
+        float ov = 0.f, lv = 0.f;
+#pragma unroll
+        for (int k = 0; k < ER_NWAVES; ++k) {
+            const float w = (wm[k] == -INFINITY) ? 0.f : expf(wm[k] - M);
+            const float* src = ored + k * 4 * D + tid;
+            ov = fmaf((src[0] + src[D]) + (src[2 * D] + src[3 * D]), w, ov);
+            lv = fmaf(wl[k], w, lv);
+        }
+        a.out[(long long)b * a.hidden + h * D + tid] = ov / lv;
+    }
+}
+
+template <int D>
+inline hipError_t launch_attn_stream_d(const AttnDecArgs& a, bool kv_half, int B, hipStream_t st) {
+    const dim3 grid(a.H, B), blk(ER_WG);
+    if (!kv_half) hipLaunchKernelGGL((attn_stream_kernel<float, D, 2>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((attn_stream_kernel<_Float16, D, 2>), grid, blk, 0, st, a);
     return hipGetLastError();
 }
 

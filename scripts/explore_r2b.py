@@ -36,6 +36,14 @@ def main():
             elif sec == "sweep1":
                 ctx = [2060, 2426, 2926, 3426, 3926, 4050, 4176, 4676, 5176, 5676, 6040]
                 attn_sweep.run(opt, sd, [{}, v3], "fp32", 1, 4000, ctx)
+            elif sec == "stream32":
+                ctx = [2176, 3176, 4176, 5176, 5926]
+                attn_sweep.run(opt, sd, [{}, {"ER_ATTN_V_BATCHED": 3}], "fp16", 32, 4000, ctx)
+                attn_sweep.run(opt, sd, [{}, {"ER_ATTN_V_BATCHED": 3}], "fp32", 32, 4000, [2176, 4176, 5926])
+                attn_sweep.run(opt, sd, [{}, {"ER_ATTN_V_BATCHED": 3}], "fp16", 8, 4000, [2176, 4176, 5926])
+            elif sec == "v3only":
+                tune_decode.run(opt, sd, [v3], "fp32", 1000)
+                attn_sweep.run(opt, sd, [v3], "fp32", 1, 4000, [2060, 2926, 3426, 4050, 4176, 5176, 6040])
             elif sec == "sweep32":
                 ctx = [2176, 3176, 3926, 4176, 4426, 5176, 5926]
                 attn_sweep.run(opt, sd, [{}, {"ER_ATTN_GRID_HS": 0}], "fp16", 32, 4000, ctx)

@@ -169,6 +169,28 @@ def test_attn_decode_fp16_cache(D, lens, steps):
         close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"fp16-KV attn row {b} len {n}")
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_attn_decode_streaming_kernel(monkeypatch, half):
+    """ER_ATTN_V_BATCHED=3: one workgroup per (row, head) walks the whole key range with a running softmax per wave
+    (double-buffered register tiles, no partials, no merge kernel).  Ragged lengths incl. 1 key and a non-multiple of the tile."""
+    from edgerunner_amd import kernels as K
+    monkeypatch.setenv("ER_ATTN_V_BATCHED", "3")
+    lens = [2051, 700, 1, 65, 6049, 128, 129, 63]
+    B, H, D = len(lens), 16, 96
+    Lcap = 6080
+    q = rnd(B, H * D, seed=70)
+    kc, vc = rnd(B, H, Lcap, D, seed=71), rnd(B, H, Lcap, D, seed=72)
+    if half:
+        kc, vc = kc.half(), vc.half()
+    for b, n in enumerate(lens):
+        kc[b, :, n:] = float("nan")
+        vc[b, :, n:] = float("nan")
+    out = K.attn_decode(q, kc, vc, lens, 4)
+    for b, n in enumerate(lens):
+        w = torch.softmax(q[b].view(H, 1, D).double() @ kc[b, :, :n].double().transpose(1, 2) / math.sqrt(D), dim=-1)
+        close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"streaming attn row {b} len {n}")
+
+
 @pytest.mark.parametrize("length,lcap,kv16,w16", [(1, 64, False, False), (17, 64, False, False), (129, 160, False, False),
                                                   (2051, 6080, False, False), (4097, 6080, False, False),
                                                   (6049, 6080, False, False), (8192, 8192, False, False),

@@ -24,7 +24,7 @@ def make_lmm(num_layers=2, seed=0, style="perturbed", precision="fp32", **kw):
     from edgerunner_amd.models import LMM
     from edgerunner_amd.options import config_defaults
     key = (num_layers, seed, style, precision, tuple(sorted(kw.items())),
-           tuple(os.environ.get(k, "") for k in ("ER_NO_GRAPH", "ER_DECODE_V", "ER_NW_QKV")))
+           tuple(os.environ.get(k, "") for k in ("ER_NO_GRAPH", "ER_DECODE_V", "ER_NW_QKV", "ER_ATTN_V_BATCHED")))
     if key not in _CACHE:
         opt = dataclasses.replace(config_defaults["ArAE"], num_layers=num_layers, generate_mode="greedy", **kw)
         m = LMM(opt, DEV, precision=precision)
@@ -259,6 +259,23 @@ def test_decode_v3_fast_mode_matches_v2(monkeypatch):
     err = max(np.abs(l3[t] - l2[t]).max() for t in l2)
     print(f"fp16 v3 vs v2 max|dlogit|: {err:.3e}")
     assert err < 1e-4
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_streaming_batched_attention_ids(gold_small, monkeypatch, precision):
+    """ER_ATTN_V_BATCHED=3 (one streaming workgroup per (row, head), no merge kernel) on an 18-row batch: rows of cloud 0
+    reproduce the golden ids (fp32) / the default batched kernels' ids (fp16), equal clouds give equal rows."""
+    batch = torch.cat([cloud(i % 3) for i in range(18)])
+    base = make_lmm(precision=precision)
+    _, ref = base.generate(batch, 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
+    monkeypatch.setenv("ER_ATTN_V_BATCHED", "3")
+    lmm = make_lmm(precision=precision)
+    _, toks = lmm.generate(batch, 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
+    for r in range(18):
+        assert_ids(toks[r], ref[r], f"{precision} row {r}: streaming vs split attention")
+    if precision == "fp32":
+        assert_ids(toks[0], gold_small["ids_min96"][0][:64], "row 0 vs the reference golden")
+    assert_ids(toks[1], toks[16], "rows 1 and 16 hold the same cloud")
 
 
 # ------------------------------------------------------------------ host callable path, sample mode
