@@ -120,10 +120,10 @@ struct er_ctx {
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_grid_hs = 1;     // attention partial kernel (v2) dispatched heads-fastest: chunks beyond the current length exit last (ER_ATTN_GRID_HS=0: chunks fastest)
     bool out_valu = false;    // ER_OUT_VALU=1: batched out_proj on the VALU kernel (round-1 choice)
-    int attn_v_batched = 1;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 1 / 2 = split kernels + merge, 3 = one streaming workgroup per (row, head), no merge
-    bool stream_attn = false; // batched && attn_v_batched == 3 && D == 96
+    int attn_v_batched = 0;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 0 = auto (streaming when B*H >= 512, else split v1), 1 / 2 = split kernels + merge, 3 = one streaming workgroup per (row, head), no merge
+    bool stream_attn = false; // batched, D == 96 and (forced or B*H >= 512: two streaming workgroups per CU)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
-    int decode_v = 2;         // ER_DECODE_V=3: balanced-chunk attention + merge fused into out_proj (single row, D = 96, 16 heads, Lcap <= 8192)
+    int decode_v = 3;         // single-row decode: 3 = balanced-chunk attention + merge fused into out_proj (one row, D = 96, 16 heads, Lcap <= 8192); ER_DECODE_V=2 = fixed 128-key chunks + merge kernel (also the fallback when the cache does not qualify)
     bool v3 = false;          // decode_v == 3 and the reserved cache qualifies
     int nch3 = 0;             // chunks per head of the balanced attention kernel
     float* part_ml = nullptr; // version 3: {m, l} of the partials
@@ -240,10 +240,10 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 1) == 0 ? 0 : 1;
-    c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 1);
-    if (c->attn_v_batched != 2 && c->attn_v_batched != 3) c->attn_v_batched = 1;
+    c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 0);
+    if (c->attn_v_batched < 0 || c->attn_v_batched > 3) c->attn_v_batched = 0;
     c->out_valu = env_int("ER_OUT_VALU", 0) == 1;
-    c->decode_v = env_int("ER_DECODE_V", 2) == 3 ? 3 : 2;
+    c->decode_v = env_int("ER_DECODE_V", 3) == 2 ? 2 : 3;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -591,7 +591,7 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     const char* bv = getenv("ER_BATCHED_VALU");
     c->batched_valu = bv && bv[0] == '1';
     if (c->batched && !c->batched_valu) ERCHK(make_tiled_weights(c));
-    c->stream_attn = c->batched && c->attn_v_batched == 3 && D == 96;
+    c->stream_attn = c->batched && D == 96 && (c->attn_v_batched == 3 || (c->attn_v_batched == 0 && batch * H >= 512));
     c->v3 = c->decode_v == 3 && batch == 1 && !c->batched && D == 96 && H == 16 && hid == 1536 && attn3_fits(Lcap, H);
     return ER_OK;
 }
@@ -765,7 +765,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             if (c->v3) return launch_attn_partial3_d<96>(attn_args(c, layer), HALF, c->nch3, B, st);
             if (c->stream_attn) return launch_attn_stream_d<96>(attn_args(c, layer), HALF, B, st);
             return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st,
-                                       (c->batched && c->attn_v_batched == 1) ? 1 : c->attn_v);
+                                       (c->batched && c->attn_v_batched != 2) ? 1 : c->attn_v);
         case 2:
             if (c->v3 || c->stream_attn) return hipSuccess;      // the merge runs inside the out_proj kernel / there are no partials
             return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);

@@ -228,10 +228,11 @@ def test_graph_replay_equals_eager(gold_small, monkeypatch):
     assert_ids(toks[0], gold_small["ids_min96"][0], "eager launches")
 
 
-# ------------------------------------------------------------------ decode version 3 (balanced attention chunks, merge fused into out_proj)
-@pytest.mark.parametrize("knobs", [{"ER_DECODE_V": "3"}, {"ER_NW_QKV": "6"}, {"ER_DECODE_V": "3", "ER_NW_QKV": "6"}])
-def test_decode_v3_and_6wave_qkv_small(gold_small, monkeypatch, knobs):
-    """The alternative single-row decode kernels behind ER_DECODE_V=3 / ER_NW_QKV=6: golden ids, teacher-forced logits."""
+# ------------------------------------------------------------------ single-row decode versions (default 3: balanced attention chunks,
+# merge fused into out_proj; ER_DECODE_V=2: fixed 128-key chunks + merge kernel, also the fallback for caches > 8192 keys)
+@pytest.mark.parametrize("knobs", [{"ER_DECODE_V": "2"}, {"ER_NW_QKV": "6"}, {"ER_DECODE_V": "2", "ER_NW_QKV": "6"}])
+def test_decode_v2_and_6wave_qkv_small(gold_small, monkeypatch, knobs):
+    """The alternative single-row decode kernels behind ER_DECODE_V=2 / ER_NW_QKV=6: golden ids, teacher-forced logits."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     lmm = make_lmm()          # separate context: the knobs are read at er_create
@@ -246,25 +247,36 @@ def test_decode_v3_and_6wave_qkv_small(gold_small, monkeypatch, knobs):
     assert err < LOGIT_TOL
 
 
-def test_decode_v3_fast_mode_matches_v2(monkeypatch):
-    """fp16 storage: the version-3 kernels against the default ones on the same context (ids equal, logits to round-off)."""
+def test_decode_versions_agree_in_fast_mode(monkeypatch):
+    """fp16 storage: the version-2 kernels against the default (version 3) ones on the same inputs (ids equal, logits to round-off)."""
     base = make_lmm(precision="fp16")
-    _, t2 = base.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
-    l2 = teacher_forced_logits(base, cloud(2), 1000, t2[0], set(range(0, 64, 7)))
-    monkeypatch.setenv("ER_DECODE_V", "3")
-    v3 = make_lmm(precision="fp16")
-    _, t3 = v3.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
-    assert_ids(t3[0], t2[0], "fp16 storage, version 3 vs version 2")
-    l3 = teacher_forced_logits(v3, cloud(2), 1000, t2[0], set(range(0, 64, 7)))
+    _, t3 = base.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
+    l3 = teacher_forced_logits(base, cloud(2), 1000, t3[0], set(range(0, 64, 7)))
+    monkeypatch.setenv("ER_DECODE_V", "2")
+    v2 = make_lmm(precision="fp16")
+    _, t2 = v2.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
+    assert_ids(t2[0], t3[0], "fp16 storage, version 2 vs version 3")
+    l2 = teacher_forced_logits(v2, cloud(2), 1000, t3[0], set(range(0, 64, 7)))
     err = max(np.abs(l3[t] - l2[t]).max() for t in l2)
-    print(f"fp16 v3 vs v2 max|dlogit|: {err:.3e}")
+    print(f"fp16 v2 vs v3 max|dlogit|: {err:.3e}")
     assert err < 1e-4
+
+
+def test_long_cache_falls_back_to_version2(gold_small):
+    """A reserved cache beyond 8192 keys does not fit the balanced kernel's 16 x 512-key chunks: the context must fall back to
+    the fixed-chunk kernels and still reproduce the golden ids."""
+    lmm = make_lmm()
+    lmm.mesh_decoder.reserve(1, 9000)
+    _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
+    assert_ids(toks[0], gold_small["ids_min96"][0], "Lcap 9000 (version-2 fallback)")
+    lmm.mesh_decoder.reserve(1, 4096)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
 def test_streaming_batched_attention_ids(gold_small, monkeypatch, precision):
     """ER_ATTN_V_BATCHED=3 (one streaming workgroup per (row, head), no merge kernel) on an 18-row batch: rows of cloud 0
-    reproduce the golden ids (fp32) / the default batched kernels' ids (fp16), equal clouds give equal rows."""
+    reproduce the golden ids (fp32) / the split kernels' ids (fp16; 18 x 16 < 512 pairs, so the default is the split kernel),
+    equal clouds give equal rows."""
     batch = torch.cat([cloud(i % 3) for i in range(18)])
     base = make_lmm(precision=precision)
     _, ref = base.generate(batch, 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
@@ -595,14 +607,14 @@ def test_config2_shape_sample_mode_distributions(gold_batch):
 
 
 # ------------------------------------------------------------------ BASELINE configs[1]: full size, T = 4000
-@pytest.mark.parametrize("decode_v", ["2", "3"])
+@pytest.mark.parametrize("decode_v", ["3", "2"])
 def test_full_size_greedy_T4000_bit_exact(gold_full, manifest, monkeypatch, decode_v):
     """ArAE 24 layers, cloud 0 (4096 pts), greedy, test_num_face=1000, 4000 new tokens with EOS
     suppressed until T: ids must equal the reference CPU-eager run bit for bit.  Both single-row decode versions
     (ER_DECODE_V: 2 = fixed 128-key chunks + merge kernel, 3 = balanced chunks + merge fused into out_proj)."""
     from edgerunner_amd.grammar import GrammarState
     from edgerunner_amd import native
-    if decode_v != "2":
+    if decode_v != "3":        # 3 is the default
         monkeypatch.setenv("ER_DECODE_V", decode_v)
     lmm = make_lmm(num_layers=24)
     want = gold_full["ids"][0]
