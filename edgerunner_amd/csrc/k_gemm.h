@@ -6,8 +6,10 @@
 //
 //   C[M,N] = epilogue( A[M,K] . op(B) )       op(B) = B^T for B [N,K] (nn.Linear weight / K-cache rows)
 //                                              op(B) = B   for B [K,N] (V rows, "NN")
-// Batched over blockIdx.z with two-level strides (batch, head).  Tile 128x128x32 in two LDS stages,
-// 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32.  Operands are staged k-major
+// Batched over blockIdx.z with two-level strides (batch, head).  Tile (64 TM) x (64 TN) x 32 in two LDS stages,
+// 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32 (TM, TN in {1, 2}: the launcher picks the largest tile that still
+// gives every CU several workgroups - the 2050-row prefill and the 4096-row DiT GEMMs have only 200-800 tiles of 128x128,
+// i.e. ONE 4-wave workgroup per CU with nothing to hide its barriers and LDS reads behind).  Operands are staged k-major
 // in LDS so that an MFMA operand fetch (lane l needs element [k = l>>5][i = l&31])
 // is a conflict-free ds_read_b32; the next k-tile is prefetched into registers while
 // the current one is multiplied.
@@ -43,22 +45,23 @@ struct GemmArgs {
     long long kv_bstride;
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = GBM + 4;
+constexpr int GBK = 32;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // epilogue shared by the fp32 and fp16-input kernels: C/D fragment map of the 32x32 MFMA (dtype independent):
 // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const f32x16 (&acc)[2][2], int m0, int n0, int wm,
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
                                               int wn, int kh, int li) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int gn = n0 + wn * 64 + j * 32 + li;
+                const int gm = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int gn = n0 + wn * 32 * TN + j * 32 + li;
                 if (gm >= g.M || gn >= g.N) continue;
                 float v = acc[i][j][r];
                 if (g.div != 0.f) v = v / g.div;
@@ -82,17 +85,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const
             }
 }
 
+template <int TM, int TN>
 __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
+    constexpr int GBM = 64 * TM, GBN = 64 * TN, GLD = GBN + 4;
     // two LDS stages: tile kt+1 is written while tile kt is multiplied -> ONE workgroup barrier per k-tile (round 1: two
     // barriers per 16-wide tile kept the matrix pipe 44 % busy)
     // LDS row strides: the transposing (k-major) stores of a thread's float4 go to 4 rows, and the 32 lanes of a store group
     // hold (k-quad 0..7, row 0..3): with a stride = 1 (mod 8) those 32 addresses fall into 32 different banks (stride 132
     // put them into 8 banks: PMC showed half of all LDS cycles were bank conflicts).  The NN B tile is stored row-wise with
     // 16-byte stores and keeps the 16-byte aligned stride.
-    constexpr int GLT = GBM + 1;
+    constexpr int GLT = GBM + 1, GLTB = GBN + 1;
     __shared__ __attribute__((aligned(16))) float As[2][GBK * GLT];
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
-    const int ldbs = g.b_is_kn ? GLD : GLT;
+    const int ldbs = g.b_is_kn ? GLD : GLTB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -110,29 +115,31 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
     const int nk = (K + GBK - 1) / GBK;       // K % 16 == 0; a trailing half tile is zero-filled
 
     // global -> register staging maps (a k-tile is GBK = 32 wide: 8 float4 per row)
-    const int ar = tid >> 3, akq = tid & 7;   // A / B(NT): row (0..31, +32 x 4), k-quad
-    const int bkr = tid >> 5, bnq = tid & 31; // B(NN): k row (0..7, +8 x 4), n-quad
-    f32x4 ra[4], rb[4];
+    constexpr int NRA = GBM / 32, NRB = GBN / 32;          // 32-row passes of the A / B(NT) tile
+    constexpr int QN = GBN / 4, RPN = ER_WG / QN;          // B(NN): n-quads per k row, k rows per pass (NRB passes cover the 32 k rows)
+    const int ar = tid >> 3, akq = tid & 7;   // A / B(NT): row (0..31, +32 per pass), k-quad
+    const int bkr = tid / QN, bnq = tid % QN; // B(NN): k row (+RPN per pass), n-quad
+    f32x4 ra[NRA], rb[NRB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * GBK;
         const bool kin = k0 + 4 * akq < K;
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
+        for (int hh = 0; hh < NRA; ++hh) {
             const int gm = m0 + ar + 32 * hh;
             ra[hh] = (gm < g.M && kin) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * akq) : zero4;
         }
         if (!g.b_is_kn) {
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
+            for (int hh = 0; hh < NRB; ++hh) {
                 const int gn = n0 + ar + 32 * hh;
                 rb[hh] = (gn < g.N && kin) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 4 * akq) : zero4;
             }
         } else {
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
-                const int gk = k0 + bkr + 8 * hh;
+            for (int hh = 0; hh < NRB; ++hh) {
+                const int gk = k0 + bkr + RPN * hh;
                 const int gn = n0 + 4 * bnq;
                 rb[hh] = (gk < g.kb_valid && gk < K && gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gk * g.ldb + gn) : zero4;
             }
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
         float* as = As[s];
         float* bs = Bs[s];
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
+        for (int hh = 0; hh < NRA; ++hh) {
             const int m = ar + 32 * hh;
             as[(4 * akq + 0) * GLT + m] = ra[hh].x;
             as[(4 * akq + 1) * GLT + m] = ra[hh].y;
@@ -151,25 +158,25 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
         }
         if (!g.b_is_kn) {
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
+            for (int hh = 0; hh < NRB; ++hh) {
                 const int n = ar + 32 * hh;
-                bs[(4 * akq + 0) * GLT + n] = rb[hh].x;
-                bs[(4 * akq + 1) * GLT + n] = rb[hh].y;
-                bs[(4 * akq + 2) * GLT + n] = rb[hh].z;
-                bs[(4 * akq + 3) * GLT + n] = rb[hh].w;
+                bs[(4 * akq + 0) * GLTB + n] = rb[hh].x;
+                bs[(4 * akq + 1) * GLTB + n] = rb[hh].y;
+                bs[(4 * akq + 2) * GLTB + n] = rb[hh].z;
+                bs[(4 * akq + 3) * GLTB + n] = rb[hh].w;
             }
         } else {
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh)
-                *reinterpret_cast<f32x4*>(&bs[(bkr + 8 * hh) * GLD + 4 * bnq]) = rb[hh];
+            for (int hh = 0; hh < NRB; ++hh)
+                *reinterpret_cast<f32x4*>(&bs[(bkr + RPN * hh) * GLD + 4 * bnq]) = rb[hh];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -184,21 +191,24 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < GBK / 2; ++kk) {
-            const float* ap = As[cur] + (2 * kk + kh) * GLT + wm * 64 + li;
-            const float* bp = Bs[cur] + (2 * kk + kh) * ldbs + wn * 64 + li;
-            const float a0 = ap[0], a1 = ap[32];
-            const float b0 = bp[0], b1 = bp[32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const float* ap = As[cur] + (2 * kk + kh) * GLT + wm * 32 * TM + li;
+            const float* bp = Bs[cur] + (2 * kk + kh) * ldbs + wn * 32 * TN + li;
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = ap[32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = bp[32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         // the other stage was last read in iteration kt-1, and every wave passed that iteration's barrier since
         if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
     }
 
-    gemm_epilogue(g, C, acc, m0, n0, wm, wn, kh, li);
+    gemm_epilogue<TM, TN>(g, C, acc, m0, n0, wm, wn, kh, li);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -212,7 +222,9 @@ constexpr int HBK = 32, HLD = 40;            // halves per LDS row (32 + 8 pad)
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
+template <int TM, int TN>
 __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
+    constexpr int GBM = 64 * TM, GBN = 64 * TN;
     // ONE LDS stage (20 KB): a k-tile is only 8 MFMAs (256 cycles) per wave, far shorter than a global-load round trip, so
     // what hides that latency is the number of workgroups per CU, not a second LDS stage (a two-stage version measured
     // slower: 21.4 vs 20.4 ms per DiT forward; PMC: the split kernel below sat at 16 % MFMA busy with two stages)
@@ -224,42 +236,43 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
     const float* A = g.A;
     const _Float16* B = reinterpret_cast<const _Float16*>(g.B);
     const int nk = g.K / HBK;
-    f32x4 ra[4];
-    f32x4 rb[2];
+    constexpr int NA = GBM / 32, NB = (GBN + 63) / 64;      // float4 of A / 16-byte pieces of B per thread and k-tile
+    f32x4 ra[NA];
+    f32x4 rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&](int kt) {
         const int k0 = kt * HBK;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NA; ++u) {
             const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
             const int gm = m0 + row;
             ra[u] = (gm < g.M) ? *reinterpret_cast<const f32x4*>(A + (long long)gm * g.lda + k0 + 4 * c4) : zero4;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NB; ++u) {
             const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
             const int gn = n0 + row;
-            rb[u] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
+            rb[u] = (gn < g.N && row < GBN) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
         }
     };
     auto store_tile = [&](int s) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NA; ++u) {
             const int idx = tid + ER_WG * u, row = idx >> 3, c4 = idx & 7;
             h16x4 hv = {(_Float16)ra[u].x, (_Float16)ra[u].y, (_Float16)ra[u].z, (_Float16)ra[u].w};
             *reinterpret_cast<h16x4*>(&As[s][row * HLD + 4 * c4]) = hv;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NB; ++u) {
             const int idx = tid + ER_WG * u, row = idx >> 2, c8 = idx & 3;
-            *reinterpret_cast<f32x4*>(&Bs[s][row * HLD + 8 * c8]) = rb[u];
+            if (row < GBN) *reinterpret_cast<f32x4*>(&Bs[s][row * HLD + 8 * c8]) = rb[u];
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (nk > 0) {
@@ -274,20 +287,21 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < HBK / 16; ++ks) {
             const int ko = ks * 16 + kh * 8;
-            const h16x8 a0 = *reinterpret_cast<const h16x8*>(&As[cur][(wm * 64 + li) * HLD + ko]);
-            const h16x8 a1 = *reinterpret_cast<const h16x8*>(&As[cur][(wm * 64 + 32 + li) * HLD + ko]);
-            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + li) * HLD + ko]);
-            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + 32 + li) * HLD + ko]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+            h16x8 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const h16x8*>(&As[cur][(wm * 32 * TM + 32 * i + li) * HLD + ko]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 32 * TN + 32 * j + li) * HLD + ko]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (kt + 1 < nk) store_tile(0);
         __syncthreads();
     }
-    gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);
+    gemm_epilogue<TM, TN>(g, g.C, acc, m0, n0, wm, wn, kh, li);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -298,8 +312,9 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16_mfma_kernel(GemmArgs g) {
 // are exact in the fp32 accumulator).  16x the fp32 matrix rate at twice the instruction count = 8x, with results within
 // fp32 round-off of the fp32-activation product - so prefill and decode keep seeing one model and the fast-mode parity
 // tests (ids exact / logits vs the fp16-STORAGE emulation) hold unchanged.  Tile 128x128x32, two LDS stages.
-template <int BK>
+template <int BK, int TM, int TN>
 __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
+    constexpr int GBM = 64 * TM, GBN = 64 * TN;
     constexpr int LDH = BK + 8;            // halves per LDS row (16-byte reads of a 16-lane group hit 16 distinct 4-bank slots for 40 and 72)
     // one LDS stage (30 KB -> 5 workgroups per CU): see gemm_f16_mfma_kernel
     __shared__ __attribute__((aligned(16))) _Float16 Ah[1][GBM * LDH];
@@ -311,7 +326,8 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
     const float* A = g.A;
     const _Float16* B = reinterpret_cast<const _Float16*>(g.B);
     const int nk = g.K / BK;
-    constexpr int NA = BK / 8, NB = BK / 16, C4 = BK / 4, C8 = BK / 8;     // float4 of A / 16-byte pieces of B per thread
+    constexpr int C4 = BK / 4, C8 = BK / 8;                                // float4 of A / 16-byte pieces of B per tile row
+    constexpr int NA = GBM * C4 / ER_WG, NB = (GBN * C8 + ER_WG - 1) / ER_WG;   // ... per thread and k-tile
     f32x4 ra[NA];
     f32x4 rb[NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
         for (int u = 0; u < NB; ++u) {
             const int idx = tid + ER_WG * u, row = idx / C8, c8 = idx % C8;
             const int gn = n0 + row;
-            rb[u] = (gn < g.N) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
+            rb[u] = (gn < g.N && row < GBN) ? *reinterpret_cast<const f32x4*>(B + (long long)gn * g.ldb + k0 + 8 * c8) : zero4;
         }
     };
     auto store_tile = [&](int s) {
@@ -343,14 +359,14 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int idx = tid + ER_WG * u, row = idx / C8, c8 = idx % C8;
-            *reinterpret_cast<f32x4*>(&Bs[s][row * LDH + 8 * c8]) = rb[u];
+            if (row < GBN) *reinterpret_cast<f32x4*>(&Bs[s][row * LDH + 8 * c8]) = rb[u];
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (nk > 0) {
@@ -365,27 +381,29 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int ko = ks * 16 + kh * 8;
-            const h16x8 b0 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + li) * LDH + ko]);
-            const h16x8 b1 = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 64 + 32 + li) * LDH + ko]);
-            const h16x8 a0h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + li) * LDH + ko]);
-            const h16x8 a1h = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 64 + 32 + li) * LDH + ko]);
-            const h16x8 a0l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + li) * LDH + ko]);
-            const h16x8 a1l = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 64 + 32 + li) * LDH + ko]);
+            h16x8 bv[TN], ah[TM], al[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const h16x8*>(&Bs[cur][(wn * 32 * TN + 32 * j + li) * LDH + ko]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const h16x8*>(&Ah[cur][(wm * 32 * TM + 32 * i + li) * LDH + ko]);
+                al[i] = *reinterpret_cast<const h16x8*>(&Al[cur][(wm * 32 * TM + 32 * i + li) * LDH + ko]);
+            }
             // the small (lo) products first, then the large ones: the accumulator sees them in increasing magnitude
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bv[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bv[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (kt + 1 < nk) store_tile(0);
         __syncthreads();
     }
-    gemm_epilogue(g, g.C, acc, m0, n0, wm, wn, kh, li);
+    gemm_epilogue<TM, TN>(g, g.C, acc, m0, n0, wm, wn, kh, li);
 }
 
 inline GemmArgs gemm_args_default() {
@@ -395,23 +413,49 @@ inline GemmArgs gemm_args_default() {
     return g;
 }
 
+// ---- tile choice.  A 128x128 tile reads the fewest operand bytes per flop, but the once-per-sample GEMMs of this path are
+// small: the 2050-row prefill has 17 x 12..48 tiles of 128x128 and the 4096-row DiT Linears 32 x 8..64, i.e. about ONE 4-wave
+// workgroup per CU, whose barriers, LDS reads and global-load latency nothing hides.  Halve the tile (first along M, then
+// along N) until every CU gets at least GEMM_MIN_WGS_PER_CU workgroups.  ER_GEMM_TILE = 1 (128x128), 2 (64x128), 3 (64x64)
+// forces a shape for A/B runs.
+constexpr int GEMM_MIN_WGS_PER_CU = 3;
+inline int gemm_pick_tile(int M, int N, int batch) {
+    static const int forced = [] { const char* v = getenv("ER_GEMM_TILE"); return v ? atoi(v) : 0; }();
+    if (forced >= 1 && forced <= 3) return forced;
+    auto wgs = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
+    const long long want = 256LL * GEMM_MIN_WGS_PER_CU;
+    if (wgs(128, 128) >= want) return 1;
+    if (wgs(64, 128) >= want) return 2;
+    return 3;
+}
+#define ER_GEMM_DISPATCH(KERNEL_T, g, batch, st)                                                                       \
+    do {                                                                                                               \
+        const int tile_ = gemm_pick_tile((g).M, (g).N, (batch));                                                       \
+        const int bm_ = tile_ == 1 ? 128 : 64, bn_ = tile_ == 3 ? 64 : 128;                                            \
+        const dim3 grid_(((g).N + bn_ - 1) / bn_, ((g).M + bm_ - 1) / bm_, (batch));                                   \
+        if (tile_ == 1) hipLaunchKernelGGL((KERNEL_T(2, 2)), grid_, dim3(ER_WG), 0, (st), (g));                        \
+        else if (tile_ == 2) hipLaunchKernelGGL((KERNEL_T(1, 2)), grid_, dim3(ER_WG), 0, (st), (g));                   \
+        else hipLaunchKernelGGL((KERNEL_T(1, 1)), grid_, dim3(ER_WG), 0, (st), (g));                                   \
+    } while (0)
+#define ER_K_F16(TM, TN) gemm_f16_mfma_kernel<TM, TN>
+#define ER_K_F16S32(TM, TN) gemm_f16s_mfma_kernel<32, TM, TN>
+#define ER_K_F16S64(TM, TN) gemm_f16s_mfma_kernel<64, TM, TN>
+#define ER_K_F32(TM, TN) gemm_f32_mfma_kernel<TM, TN>
+
 inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT only, K % 32 == 0, B = fp16 weights
-    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, 1);
-    hipLaunchKernelGGL(gemm_f16_mfma_kernel, grid, dim3(ER_WG), 0, st, g);
+    ER_GEMM_DISPATCH(ER_K_F16, g, 1, st);
     return hipGetLastError();
 }
 
 inline hipError_t launch_gemm_f16s(const GemmArgs& g, hipStream_t st) {  // NT only, K % 32 == 0, B = fp16 weights, A split hi/lo
-    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, 1);
     static const bool bk64 = [] { const char* v = getenv("ER_F16S_BK"); return v && atoi(v) == 64; }();
-    if (bk64 && g.K % 64 == 0) hipLaunchKernelGGL((gemm_f16s_mfma_kernel<64>), grid, dim3(ER_WG), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f16s_mfma_kernel<32>), grid, dim3(ER_WG), 0, st, g);
+    if (bk64 && g.K % 64 == 0) ER_GEMM_DISPATCH(ER_K_F16S64, g, 1, st);
+    else ER_GEMM_DISPATCH(ER_K_F16S32, g, 1, st);
     return hipGetLastError();
 }
 
 inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
-    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch);
-    hipLaunchKernelGGL(gemm_f32_mfma_kernel, grid, dim3(ER_WG), 0, st, g);
+    ER_GEMM_DISPATCH(ER_K_F32, g, batch, st);
     return hipGetLastError();
 }
 
