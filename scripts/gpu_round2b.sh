@@ -16,6 +16,20 @@ for SEC in "$@"; do
     parity)
       timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -p no:cacheprovider --timeout 600 \
         -k "${PARITY_K:-decode_v3 or (full_size and 3)}" 2>&1 | filt | tail -40 | tee gpurun_out/r2b_parity.log ;;
+    gemmtest)
+      timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_dit.py -q -m gpu -p no:cacheprovider --timeout 600 -k "gemm or flash or fp16_mfma or forward" 2>&1 | filt | tail -15 | tee gpurun_out/r2b_gemmtest.log ;;
+    gemmab)     # tile-shape A/B of the once-per-sample GEMMs: ER_GEMM_TILE=1 is the old fixed 128x128 tile, 0 = workgroups-per-CU driven choice
+      for T in 1 0; do
+        echo "--- ER_GEMM_TILE=$T"
+        ER_GEMM_TILE=$T timeout 300 python scripts/prefill_time.py fp32 1,8 2>&1 | filt | tail -3
+        ER_GEMM_TILE=$T timeout 300 python scripts/prefill_time.py fp16 1,8 2>&1 | filt | tail -3
+        ER_GEMM_TILE=$T timeout 600 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1
+      done 2>&1 | tee gpurun_out/r2b_gemmab.log ;;
+    kernarg)    # where the kernel arguments live (host-visible vs device memory) changes what a dependent launch has to fetch first
+      for V in 0 1; do
+        echo "--- HIP_FORCE_DEV_KERNARG=$V"
+        HIP_FORCE_DEV_KERNARG=$V TUNE_TOKENS=1000 TUNE_CONFIGS='[]' timeout 300 python scripts/tune_decode.py 2>&1 | filt | tail -1 | cut -c1-420
+      done 2>&1 | tee gpurun_out/r2b_kernarg.log ;;
     *) echo "unknown section $SEC" ;;
   esac
 done
