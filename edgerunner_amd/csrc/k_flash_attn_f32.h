@@ -34,10 +34,13 @@ struct Flash32Args {
 typedef float fa32_acc __attribute__((ext_vector_type(16)));
 constexpr int FA32_KT = 64, FA32_QW = 32;   // keys per tile, queries per wave
 
-// grid (ceil(N / 128), H, B), 256 threads: wave w owns queries [128 * tile + 32 * w, +32).  Causal launches walk the
-// query tiles from the last (longest key range) to the first so the long workgroups start first.
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(ER_WG) void flash_attn_f32_kernel(Flash32Args a) {
+// grid (ceil(N / (32 NWV)), H, B), 64 NWV threads: wave w owns queries [32 NWV * tile + 32 * w, +32).  Causal launches walk
+// the query tiles from the last (longest key range) to the first so the long workgroups start first.  NWV = 4 shares a
+// staged key tile between 128 queries; NWV = 2 re-stages it twice as often but doubles the number of workgroups, which is
+// what a single 2050-token prefill needs (17 x 16 four-wave workgroups = one per CU with nothing to overlap).
+template <int D, bool CAUSAL, int NWV>
+__global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a) {
+    constexpr int THREADS = 64 * NWV;
     constexpr int LD = D + 4;               // LDS row stride (floats), LD/4 odd -> the 16-byte K reads of a 16-lane group hit 16 distinct 4-bank slots
     constexpr int HD = D / 2, NDB = D / 32, F4 = D / 4;
     static_assert(D % 32 == 0 && (LD % 8) == 4, "head_dim 64 or 96: LD/4 must be odd");
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f32_kernel(Flash32Args a) {
     const int li = lane & 31, half = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
     const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-    const int q0 = qt * (ER_NWAVES * FA32_QW) + wid * FA32_QW;
+    const int q0 = qt * (NWV * FA32_QW) + wid * FA32_QW;
     const float* Q = a.Q + b * a.qs_b + h * a.qs_h;
     const float* K = a.K + b * a.ks_b + h * a.ks_h;
     const float* V = a.V + b * a.vs_b + h * a.vs_h;
@@ -72,20 +75,21 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f32_kernel(Flash32Args a) {
     float m_run = -INFINITY, l_run = 0.f;    // l_run covers this lane half's keys only
 
     // keys any query of this WORKGROUP can see
-    const int wg_last_q = min(a.N - 1, qt * (ER_NWAVES * FA32_QW) + ER_NWAVES * FA32_QW - 1);
+    const int wg_last_q = min(a.N - 1, qt * (NWV * FA32_QW) + NWV * FA32_QW - 1);
     const int kmax = CAUSAL ? min(a.M, wg_last_q + a.causal_off + 1) : a.M;
     const int ntiles = (kmax + FA32_KT - 1) / FA32_KT;
     const int wave_last_key = CAUSAL ? (q0 + FA32_QW - 1 + a.causal_off) : (a.M - 1);   // beyond it this wave has nothing to do
 
     // global -> register staging of one key tile (issued a whole tile ahead: the loads of tile t+1 are in flight while
     // tile t is multiplied; one wave per SIMD has no other wave to hide that latency behind)
-    constexpr int NST = (FA32_KT * F4) / ER_WG;
+    constexpr int NST = (FA32_KT * F4) / THREADS;
+    static_assert((FA32_KT * F4) % THREADS == 0, "staging loop shape");
     f32x4 kst[NST], vst[NST];
     auto load_tile = [&](int t) {
         const int kb0 = t * FA32_KT;
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
-            const int idx = tid + ER_WG * u, key = idx / F4, c4 = idx - key * F4;
+            const int idx = tid + THREADS * u, key = idx / F4, c4 = idx - key * F4;
             const int gk = min(kb0 + key, a.M - 1);
             kst[u] = *reinterpret_cast<const f32x4*>(K + (long long)gk * a.ldk + 4 * c4);
             vst[u] = *reinterpret_cast<const f32x4*>(V + (long long)gk * a.ldv + 4 * c4);
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f32_kernel(Flash32Args a) {
         __syncthreads();                     // previous tile fully consumed
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
-            const int idx = tid + ER_WG * u, key = idx / F4, c4 = idx - key * F4;
+            const int idx = tid + THREADS * u, key = idx / F4, c4 = idx - key * F4;
             *reinterpret_cast<f32x4*>(&Ks[key * LD + 4 * c4]) = kst[u];
             *reinterpret_cast<f32x4*>(&Vs[key * LD + 4 * c4]) = vst[u];
         }
@@ -176,12 +180,24 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f32_kernel(Flash32Args a) {
 }
 
 inline hipError_t launch_flash_attn_f32(const Flash32Args& a, int D, bool causal, int H, int B, hipStream_t st) {
-    dim3 grid((a.N + ER_NWAVES * FA32_QW - 1) / (ER_NWAVES * FA32_QW), H, B);
-    if (D == 96 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<96, true>), grid, dim3(ER_WG), 0, st, a);
-    else if (D == 96) hipLaunchKernelGGL((flash_attn_f32_kernel<96, false>), grid, dim3(ER_WG), 0, st, a);
-    else if (D == 64 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<64, true>), grid, dim3(ER_WG), 0, st, a);
-    else if (D == 64) hipLaunchKernelGGL((flash_attn_f32_kernel<64, false>), grid, dim3(ER_WG), 0, st, a);
-    else return hipErrorInvalidValue;
+    // two-wave workgroups while four-wave ones would leave fewer than three per CU (ER_FLASH32_NWV = 2 / 4 forces one)
+    static const int forced = [] { const char* v = getenv("ER_FLASH32_NWV"); return v ? atoi(v) : 0; }();
+    const long long wg4 = (long long)((a.N + 4 * FA32_QW - 1) / (4 * FA32_QW)) * H * B;
+    const int nwv = (forced == 2 || forced == 4) ? forced : (wg4 < 768 ? 2 : 4);
+    dim3 grid((a.N + nwv * FA32_QW - 1) / (nwv * FA32_QW), H, B), blk(64 * nwv);
+    if (nwv == 4) {
+        if (D == 96 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<96, true, 4>), grid, blk, 0, st, a);
+        else if (D == 96) hipLaunchKernelGGL((flash_attn_f32_kernel<96, false, 4>), grid, blk, 0, st, a);
+        else if (D == 64 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<64, true, 4>), grid, blk, 0, st, a);
+        else if (D == 64) hipLaunchKernelGGL((flash_attn_f32_kernel<64, false, 4>), grid, blk, 0, st, a);
+        else return hipErrorInvalidValue;
+    } else {
+        if (D == 96 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<96, true, 2>), grid, blk, 0, st, a);
+        else if (D == 96) hipLaunchKernelGGL((flash_attn_f32_kernel<96, false, 2>), grid, blk, 0, st, a);
+        else if (D == 64 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<64, true, 2>), grid, blk, 0, st, a);
+        else if (D == 64) hipLaunchKernelGGL((flash_attn_f32_kernel<64, false, 2>), grid, blk, 0, st, a);
+        else return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

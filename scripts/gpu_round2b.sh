@@ -30,6 +30,17 @@ for SEC in "$@"; do
         echo "--- HIP_FORCE_DEV_KERNARG=$V"
         HIP_FORCE_DEV_KERNARG=$V TUNE_TOKENS=1000 TUNE_CONFIGS='[]' timeout 300 python scripts/tune_decode.py 2>&1 | filt | tail -1 | cut -c1-420
       done 2>&1 | tee gpurun_out/r2b_kernarg.log ;;
+    gemmab2)    # forced tile shapes (2 = 64x128, 3 = 64x64) and the 2-wave / 4-wave fp32 flash attention, B = 1 prefill + DiT
+      for T in 0 2 3; do
+        echo "--- ER_GEMM_TILE=$T"
+        ER_GEMM_TILE=$T timeout 300 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1
+        ER_GEMM_TILE=$T timeout 300 python scripts/prefill_time.py fp16 1 2>&1 | filt | tail -1
+        ER_GEMM_TILE=$T timeout 600 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1
+      done 2>&1 | tee gpurun_out/r2b_gemmab2.log
+      echo "--- ER_FLASH32_NWV=4 (auto picks 2 at B = 1)"
+      ER_FLASH32_NWV=4 timeout 300 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1 | tee -a gpurun_out/r2b_gemmab2.log ;;
+    nwqkv)
+      TUNE_TOKENS=4000 TUNE_CONFIGS='[{"ER_NW_QKV":6},{},{"ER_NW_QKV":6}]' timeout 600 python scripts/tune_decode.py 2>&1 | filt | cut -c1-330 | tee gpurun_out/r2b_nwqkv.log ;;
     *) echo "unknown section $SEC" ;;
   esac
 done
