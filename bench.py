@@ -208,7 +208,7 @@ def kernel_names(precision, batched):
     if batched:     # B*16 >= 512: one streaming workgroup per (row, head); smaller batches keep the split round-1 kernel (er_api.hip, kind 1)
         return {"attn_decode": [f"attn_stream_kernel<{wt}, 96, 2>", f"attn_decode_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
     if os.environ.get("ER_DECODE_V", "3") != "2":     # default: balanced chunks, merge fused into out_proj (no merge kernel)
-        return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, 4>"],
+        return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, 6>"],
                 "attn_decode": [f"attn_decode3_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}, 16>"],
                 "out_proj_gemv": [f"outproj_merge_kernel<{wt}, 96, 16>"],
                 "fc1_gemv": [f"gemv_kernel<{wt}, 1, 1, 2, 1, 1, 4>"], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
@@ -329,7 +329,8 @@ def main(argv=None):
 
     # ---- roofline of the dominant decode kernel over the run that was timed.  The context grows linearly from
     # L0 + 1 to L0 + T keys over the run.  The weight-streaming kernels do not depend on it; the attention kernels do,
-    # and NOT linearly (the number of active 128-key workgroups, n = ceil(L / 128) per head, steps against the 256 CUs),
+    # and NOT linearly (the balanced kernel's load steps per wave, ceil(L / 16 / 128), step with the context; the version-2
+    # kernel's active 128-key workgroups, n = ceil(L / 128) per head, step against the 256 CUs),
     # so their run-average duration - what `rocprofv3 --stats` reports for the same command - is measured as the mean over
     # NS contexts spread evenly over the run (midpoints of NS equal segments), each a hipGraph replay of the 24 launches of
     # a kind with HIP events on the launch stream (all 24 layers' data, so nothing is cache-resident).  `achieved` =

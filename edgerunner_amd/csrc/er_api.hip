@@ -113,7 +113,7 @@ struct er_ctx {
     float* skpart = nullptr;  // split-K partials of the batched fc2
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
-    int nw_qkv = 4, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV / ER_NW_OUT: 3 or 4)
+    int nw_qkv = 6, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV: 3, 4 or 6 - 6 waves x 1 row = 768 workgroups, 3 per CU; ER_NW_OUT: 3 or 4)
     bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
     bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
@@ -226,8 +226,8 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->use_graph = !(ng && ng[0] == '1');
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
     c->rw_qkv = env_int("ER_RW_QKV", 1);
-    c->nw_qkv = env_int("ER_NW_QKV", 4);
-    if (c->nw_qkv != 3 && c->nw_qkv != 6) c->nw_qkv = 4;
+    c->nw_qkv = env_int("ER_NW_QKV", 6);
+    if (c->nw_qkv != 3 && c->nw_qkv != 4) c->nw_qkv = 6;
     c->nw_out = env_int("ER_NW_OUT", 3) == 4 ? 4 : 3;
     c->rw_fc1 = env_int("ER_RW_FC1", 2);
     c->rw_fc2 = env_int("ER_RW_FC2", 2);

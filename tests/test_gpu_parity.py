@@ -230,9 +230,9 @@ def test_graph_replay_equals_eager(gold_small, monkeypatch):
 
 # ------------------------------------------------------------------ single-row decode versions (default 3: balanced attention chunks,
 # merge fused into out_proj; ER_DECODE_V=2: fixed 128-key chunks + merge kernel, also the fallback for caches > 8192 keys)
-@pytest.mark.parametrize("knobs", [{"ER_DECODE_V": "2"}, {"ER_NW_QKV": "6"}, {"ER_DECODE_V": "2", "ER_NW_QKV": "6"}])
-def test_decode_v2_and_6wave_qkv_small(gold_small, monkeypatch, knobs):
-    """The alternative single-row decode kernels behind ER_DECODE_V=2 / ER_NW_QKV=6: golden ids, teacher-forced logits."""
+@pytest.mark.parametrize("knobs", [{"ER_DECODE_V": "2"}, {"ER_NW_QKV": "4"}, {"ER_DECODE_V": "2", "ER_NW_QKV": "4"}])
+def test_decode_v2_and_4wave_qkv_small(gold_small, monkeypatch, knobs):
+    """The alternative single-row decode kernels behind ER_DECODE_V=2 / ER_NW_QKV=4: golden ids, teacher-forced logits."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     lmm = make_lmm()          # separate context: the knobs are read at er_create
