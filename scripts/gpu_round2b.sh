@@ -41,6 +41,10 @@ for SEC in "$@"; do
       ER_FLASH32_NWV=4 timeout 300 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1 | tee -a gpurun_out/r2b_gemmab2.log ;;
     nwqkv)
       TUNE_TOKENS=4000 TUNE_CONFIGS='[{"ER_NW_QKV":6},{},{"ER_NW_QKV":6}]' timeout 600 python scripts/tune_decode.py 2>&1 | filt | cut -c1-330 | tee gpurun_out/r2b_nwqkv.log ;;
+    long32)     # BASELINE configs[2] (B = 32, sample, T = 16000, fp16): streaming vs split attention at long contexts, then the full-size run
+      SWEEP_B=32 SWEEP_T=16000 SWEEP_PRECISION=fp16 SWEEP_CONTEXTS='[6000, 10000, 14000, 18000]' SWEEP_CONFIGS='[{"ER_ATTN_V_BATCHED": 1}]' \
+        timeout 300 python scripts/attn_sweep.py 2>&1 | filt | tee gpurun_out/r2b_long32_sweep.log
+      timeout 260 python scripts/bench_batch.py 32 16000 4000 fp16 sample 2>&1 | filt | tee gpurun_out/r2b_config2_full.log ;;
     *) echo "unknown section $SEC" ;;
   esac
 done
