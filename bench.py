@@ -424,7 +424,7 @@ def main(argv=None):
         except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the bench line
             out["batch32_fp16"] = {"error": repr(e)[:200]}
         # BASELINE configs[2]'s shape (B = 32, SAMPLE mode top-k 10, test_num_face = 4000, fp16) at a reduced length: the
-        # full T = 16000 run takes 150 s (profiles/r02_config3_B32_T16000_fp16_sample.log: 3.47k tok/s = 66 % of 8 TB/s)
+        # full T = 16000 run takes 143 s (profiles/r02_config3_B32_T16000_fp16_sample.log: 3.58k tok/s = 68 % of 8 TB/s)
         try:
             Bx, Tx = 32, 1024
             sopt = dataclasses.replace(opt, generate_mode="sample")
