@@ -205,15 +205,17 @@ def kernel_names(precision, batched):
     """rocprofv3 names of the decode kernels per kind for this build's default knobs (scripts/roofline_from_rocprof.py and
     the PMC summary are matched on them); gemv_kernel<WT, KS, NB, RW, PRO, EPI, NW>."""
     wt = "float" if precision == "fp32" else "_Float16"
+    nwq = os.environ.get("ER_NW_QKV", "6")
+    nwq = nwq if nwq in ("3", "4") else "6"      # er_create's rule
     if batched:     # B*16 >= 512: one streaming workgroup per (row, head); smaller batches keep the split round-1 kernel (er_api.hip, kind 1)
         return {"attn_decode": [f"attn_stream_kernel<{wt}, 96, 2>", f"attn_decode_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
     if os.environ.get("ER_DECODE_V", "3") != "2":     # default: balanced chunks, merge fused into out_proj (no merge kernel)
-        return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, 6>"],
+        return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, {nwq}>"],
                 "attn_decode": [f"attn_decode3_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}, 16>"],
                 "out_proj_gemv": [f"outproj_merge_kernel<{wt}, 96, 16>"],
                 "fc1_gemv": [f"gemv_kernel<{wt}, 1, 1, 2, 1, 1, 4>"], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
                 "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 0, 4>"], "sample_head": ["sample_head_kernel"]}
-    return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, 4>"],
+    return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, {nwq}>"],
             "attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"],
             "attn_combine": ["attn_combine2_kernel<96>"],
             "out_proj_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 0, 2, 3>"],

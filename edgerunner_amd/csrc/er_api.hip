@@ -1461,8 +1461,8 @@ extern "C" int er_k_attn_outproj3(const float* q, const void* k, const void* v, 
     hipStream_t st = (hipStream_t)stream;
     const int nch = attn3_num_chunks(H);
     float *part = nullptr, *part_ml = nullptr;
-    HIPCHK(hipMalloc(&part, (size_t)H * nch * D * 4));
-    HIPCHK(hipMalloc(&part_ml, (size_t)H * nch * 2 * 4));
+    HIPCHK(hipMalloc(&part, (size_t)H * nch * (D + 2) * 4));
+    part_ml = part + (size_t)H * nch * D;      // one allocation: nothing to leak on an error path
     AttnDecArgs a{};
     a.q = q; a.kcache = k; a.vcache = v; a.fixed_len = len; a.part = part; a.part_ml = part_ml;
     a.H = H; a.l_cap = l_cap; a.hidden = H * D; a.kv_bstride = (long long)H * l_cap * D; a.sqrt_d = sqrtf((float)D);
@@ -1472,7 +1472,6 @@ extern "C" int er_k_attn_outproj3(const float* q, const void* k, const void* v, 
     if (e == hipSuccess) e = w_half ? launch_outproj_merge<_Float16, D>(m, nch, st) : launch_outproj_merge<float, D>(m, nch, st);
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(part);
-    hipFree(part_ml);
     HIPRET(e);
     HIPRET(e2);
     return ER_OK;

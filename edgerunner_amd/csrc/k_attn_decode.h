@@ -588,6 +588,7 @@ inline bool attn3_fits(int l_cap, int heads) { return l_cap <= attn3_num_chunks(
 
 template <int D>
 inline hipError_t launch_attn_partial3_d(const AttnDecArgs& a, bool kv_half, int nch, int B, hipStream_t st) {
+    if (nch <= 0 || a.l_cap > nch * ATTN3_CAP || !a.part_ml) return hipErrorInvalidValue;   // a chunk must fit one workgroup's wave-steps
     const dim3 grid(a.H, nch, B), blk(64 * ATTN3_NW);
     if (!kv_half) hipLaunchKernelGGL((attn_decode3_kernel<float, D, 4, ATTN3_NW>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((attn_decode3_kernel<_Float16, D, 2, ATTN3_NW>), grid, blk, 0, st, a);
@@ -614,14 +615,14 @@ __device__ __forceinline__ void attn_stream_load(AttnTile<KT, D, STEPS>& t, cons
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK), KPW = 64 / LPK;
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
-        const int kk = min(kbase + (i * ER_NWAVES + wid) * KPW + g, len - 1);    // clamped: never reads the unused tail
+        const int kk = max(0, min(kbase + (i * ER_NWAVES + wid) * KPW + g, len - 1));    // clamped: never reads the unused tail
         const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)kk * D);
 #pragma unroll
         for (int j = 0; j < NV; ++j) t.k[i][j] = __builtin_nontemporal_load(kr + j * LPK + p);
     }
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
-        const int kk = min(kbase + (i * ER_NWAVES + wid) * KPW + g, len - 1);
+        const int kk = max(0, min(kbase + (i * ER_NWAVES + wid) * KPW + g, len - 1));
         const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)kk * D);
 #pragma unroll
         for (int j = 0; j < NV; ++j) t.v[i][j] = __builtin_nontemporal_load(vr + j * LPK + p);
