@@ -533,6 +533,41 @@ static int make_tiled_weights(er_ctx* c) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ which decode kernels a cache shape gets
+// ONE place for the selection rules (kv_alloc applies them, er_plan_decode reports them; pure host logic):
+//   batched     : B > 4 (or forced) - weights streamed once per pass of 32 rows on the matrix cores
+//   version 3   : one row, 16 heads of 96, hidden 1536, reserved cache <= 16 chunks x 512 keys; else version 2
+//   attention B>4: streaming kernel when forced or (auto and B * heads >= 512: two workgroups per CU), else split + merge
+static void plan_decode(int decode_v, int attn_v_batched, bool force_batched, int batch, int H, int D, int hid, int Lcap,
+                        er_decode_plan* p) {
+    p->batched = (batch > 4 || force_batched) ? 1 : 0;
+    p->attn_chunks = attn3_num_chunks(H);
+    const bool v3 = decode_v == 3 && batch == 1 && !p->batched && D == 96 && H == 16 && hid == 1536 && attn3_fits(Lcap, H);
+    p->decode_version = v3 ? 3 : 2;
+    const bool stream = p->batched && D == 96 && (attn_v_batched == 3 || (attn_v_batched == 0 && batch * H >= 512));
+    p->attn_kernel = !p->batched ? (v3 ? ER_ATTN_BALANCED : ER_ATTN_SPLIT2)
+                                 : (stream ? ER_ATTN_STREAM : (attn_v_batched == 2 ? ER_ATTN_SPLIT2 : ER_ATTN_SPLIT1));
+    p->merge_launch = (p->attn_kernel == ER_ATTN_SPLIT1 || p->attn_kernel == ER_ATTN_SPLIT2) ? 1 : 0;
+    p->launches_per_layer = p->batched ? 0 : 5 + p->merge_launch;       // qkv, attention, (merge,) out_proj, fc1, fc2
+}
+
+static int env_int_(const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; }
+
+extern "C" int er_plan_decode(int batch, int heads, int head_dim, int hidden, int l_cap, er_decode_plan* out) {
+    if (!out || batch <= 0 || heads <= 0 || head_dim <= 0 || l_cap <= 0) return fail(ER_ERR_INVALID, "er_plan_decode: bad argument");
+    int dv = env_int_("ER_DECODE_V", 3) == 2 ? 2 : 3;
+    int avb = env_int_("ER_ATTN_V_BATCHED", 0);
+    if (avb < 0 || avb > 3) avb = 0;
+    const char* fb = getenv("ER_FORCE_BATCHED");
+    plan_decode(dv, avb, fb && fb[0] == '1', batch, heads, head_dim, hidden, (l_cap + 31) / 32 * 32, out);
+    return ER_OK;
+}
+
+extern "C" int er_plan_gemm_tile(int m, int n, int batch) {
+    if (m <= 0 || n <= 0 || batch <= 0) return fail(ER_ERR_INVALID, "er_plan_gemm_tile: bad argument");
+    return gemm_pick_tile(m, n, batch);
+}
+
 // ------------------------------------------------------------------------------------ KV cache / workspace
 static int kv_alloc(er_ctx* c, int batch, int Lcap);
 
@@ -587,12 +622,14 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     c->Lcap = Lcap;
     c->have_hidden = false;
     const char* fb = getenv("ER_FORCE_BATCHED");
-    c->batched = batch > 4 || (fb && fb[0] == '1');
+    er_decode_plan plan{};
+    plan_decode(c->decode_v, c->attn_v_batched, fb && fb[0] == '1', batch, H, D, hid, Lcap, &plan);
+    c->batched = plan.batched != 0;
     const char* bv = getenv("ER_BATCHED_VALU");
     c->batched_valu = bv && bv[0] == '1';
     if (c->batched && !c->batched_valu) ERCHK(make_tiled_weights(c));
-    c->stream_attn = c->batched && D == 96 && (c->attn_v_batched == 3 || (c->attn_v_batched == 0 && batch * H >= 512));
-    c->v3 = c->decode_v == 3 && batch == 1 && !c->batched && D == 96 && H == 16 && hid == 1536 && attn3_fits(Lcap, H);
+    c->stream_attn = plan.attn_kernel == ER_ATTN_STREAM;
+    c->v3 = plan.decode_version == 3;
     return ER_OK;
 }
 

@@ -201,6 +201,23 @@ int er_dit_forward(er_dit_ctx* ctx, const float* x_dev, const float* c_dev, cons
 int er_dit_sample(er_dit_ctx* ctx, const float* cond_dev, int batch, int m_tokens, float* latents_dev,
                   int num_inference_steps, float guidance_scale, int init_step, void* stream);
 
+/* ---- which kernels a decode context of this shape runs (pure host logic: callable without a device) ----
+ * The rules live in ONE function that er_kv_reserve applies and this entry point reports; the environment knobs of
+ * er_create (ER_DECODE_V, ER_ATTN_V_BATCHED, ER_FORCE_BATCHED) are honoured, l_cap is rounded up to 32 like er_kv_reserve. */
+typedef enum { ER_ATTN_SPLIT1 = 1, ER_ATTN_SPLIT2 = 2, ER_ATTN_BALANCED = 3, ER_ATTN_STREAM = 4 } er_attn_kernel;
+typedef struct {
+    int32_t batched;            /* 1: B > 4 path (matrix-core projections, weights once per 32 rows) */
+    int32_t decode_version;     /* single-row path: 3 = balanced chunks + merge fused into out_proj, 2 = fixed chunks + merge kernel */
+    int32_t attn_kernel;        /* er_attn_kernel */
+    int32_t attn_chunks;        /* chunks per head of the balanced kernel */
+    int32_t merge_launch;       /* 1: the attention partials are merged by their own launch */
+    int32_t launches_per_layer; /* single-row path only (0 when batched: the count depends on the row passes); a token is
+                                   layers x this + lm_head + sample_head launches */
+} er_decode_plan;
+int er_plan_decode(int batch, int heads, int head_dim, int hidden, int l_cap, er_decode_plan* out);
+/* tile shape launch_gemm* picks for an [m, n] output in `batch` slices: 1 = 128x128, 2 = 64x128, 3 = 64x64 (ER_GEMM_TILE forces) */
+int er_plan_gemm_tile(int m, int n, int batch);
+
 /* ---- measurement ---- */
 #define ER_NUM_KERNEL_KINDS 8
 /* kinds: 0 qkv_gemv 1 attn_decode 2 attn_combine 3 out_proj_gemv 4 fc1_gemv 5 fc2_gemv 6 lm_head_gemv 7 sample_head */

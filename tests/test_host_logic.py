@@ -225,3 +225,68 @@ def test_clean_like_trimesh_multibody_and_reference_fixtures():
     # empty input
     ev, ef = meto.clean_like_trimesh(np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64))
     assert len(ev) == 0 and len(ef) == 0
+
+
+# ------------------------------------------------------------------ kernel selection rules (pure host logic behind the C ABI)
+def _plan(batch, l_cap, heads=16, head_dim=96, hidden=1536):
+    from edgerunner_amd import native
+    lib = native.load_library()
+    p = native.ErDecodePlan()
+    native.check(lib.er_plan_decode(batch, heads, head_dim, hidden, l_cap, p), "er_plan_decode")
+    return p
+
+
+def test_decode_plan_single_row_versions(monkeypatch):
+    from edgerunner_amd import native
+    for k in ("ER_DECODE_V", "ER_ATTN_V_BATCHED", "ER_FORCE_BATCHED"):
+        monkeypatch.delenv(k, raising=False)
+    p = _plan(1, 2050 + 4000 + 1)                         # BASELINE configs[1]
+    assert (p.batched, p.decode_version, p.attn_kernel, p.merge_launch, p.launches_per_layer) == (0, 3, native.ER_ATTN_BALANCED, 0, 5)
+    assert p.attn_chunks == 16
+    assert _plan(1, 8192).decode_version == 3             # 16 chunks x 512 keys
+    q = _plan(1, 8193)                                    # does not fit: fixed chunks + merge kernel
+    assert (q.decode_version, q.attn_kernel, q.merge_launch, q.launches_per_layer) == (2, native.ER_ATTN_SPLIT2, 1, 6)
+    assert _plan(3, 4096).decode_version == 2             # rows 2..4 share the weights through the NB groups of version 2
+    assert _plan(1, 4096, heads=24, head_dim=64).decode_version == 2
+    monkeypatch.setenv("ER_DECODE_V", "2")
+    assert _plan(1, 6051).decode_version == 2
+    monkeypatch.delenv("ER_DECODE_V")
+    monkeypatch.setenv("ER_FORCE_BATCHED", "1")
+    f = _plan(1, 6051)
+    assert (f.batched, f.decode_version, f.attn_kernel) == (1, 2, native.ER_ATTN_SPLIT1)
+
+
+def test_decode_plan_batched_attention(monkeypatch):
+    from edgerunner_amd import native
+    for k in ("ER_DECODE_V", "ER_ATTN_V_BATCHED", "ER_FORCE_BATCHED"):
+        monkeypatch.delenv(k, raising=False)
+    assert _plan(32, 6051).attn_kernel == native.ER_ATTN_STREAM          # 512 (row, head) pairs: two workgroups per CU
+    assert _plan(32, 18051).attn_kernel == native.ER_ATTN_STREAM         # configs[2]
+    p = _plan(31, 6051)
+    assert (p.batched, p.attn_kernel, p.merge_launch) == (1, native.ER_ATTN_SPLIT1, 1)
+    assert _plan(5, 6051).attn_kernel == native.ER_ATTN_SPLIT1
+    assert _plan(4, 6051).batched == 0
+    monkeypatch.setenv("ER_ATTN_V_BATCHED", "3")
+    assert _plan(8, 6051).attn_kernel == native.ER_ATTN_STREAM
+    monkeypatch.setenv("ER_ATTN_V_BATCHED", "1")
+    assert _plan(32, 6051).attn_kernel == native.ER_ATTN_SPLIT1
+    monkeypatch.setenv("ER_ATTN_V_BATCHED", "2")
+    assert _plan(32, 6051).attn_kernel == native.ER_ATTN_SPLIT2
+
+
+def test_gemm_tile_choice_follows_workgroups_per_cu():
+    """128x128 while it leaves >= 3 workgroups per CU (768), else 64x128, else 64x64."""
+    from edgerunner_amd import native
+    import os
+    if os.environ.get("ER_GEMM_TILE"):
+        pytest.skip("ER_GEMM_TILE forces a shape")
+    lib = native.load_library()
+    tile = lambda m, n, b=1: lib.er_plan_gemm_tile(m, n, b)
+    assert tile(2050, 6144) == 1          # prefill fc1: 17 x 48 = 816 tiles of 128x128
+    assert tile(2050, 4608) == 2          # prefill qkv: 612 -> 33 x 36 = 1188 tiles of 64x128
+    assert tile(2050, 1536) == 3          # prefill out_proj / fc2: 204 -> 396 -> 64x64
+    assert tile(4096, 1024) == 3          # DiT width-1024 Linears on the CFG batch
+    assert tile(4096, 3072) == 1          # 32 x 24 = 768
+    assert tile(32 * 2050, 1536) == 1     # a 32-sample prefill
+    assert tile(2048, 2048, 16) == 1      # batched over heads
+    assert lib.er_plan_gemm_tile(0, 5, 1) < 0
