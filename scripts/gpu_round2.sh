@@ -37,7 +37,10 @@ for SEC in "$@"; do
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r02 -- python $ROOT/bench.py --steps 1 --warmup 0 --cpu-steps 0 --no-fast-extra > $ROOT/gpurun_out/rocprof_bench.json 2> $ROOT/gpurun_out/rocprof.err)
       mkdir -p gpurun_out/prof; find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
       head -12 gpurun_out/prof/*kernel_stats.csv 2>/dev/null | cut -c1-160; tail -1 gpurun_out/rocprof_bench.json | cut -c1-600
-      python scripts/roofline_from_rocprof.py $(ls gpurun_out/prof/*kernel_stats.csv | head -1) gpurun_out/rocprof_bench.json 2>&1 | tee gpurun_out/roofline_check.log ;;
+      # compare with the UNPROFILED bench line of this call when there is one (section `bench` before `prof`): the HIP-event sweep
+      # inside a traced process can be inflated by the tracer (final run of round 2: 17 us vs 11 us in the CSV and in the unprofiled line)
+      REF=gpurun_out/rocprof_bench.json; [ -s gpurun_out/bench.json ] && REF=gpurun_out/bench.json
+      python scripts/roofline_from_rocprof.py $(ls gpurun_out/prof/*kernel_stats.csv | head -1) $REF 2>&1 | tee gpurun_out/roofline_check.log ;;
     profpre)   # kernel breakdown of encode + prefill (short decode), exact and fast mode
       for PR in fp32 fp16; do
         rm -rf /tmp/profpre_$PR
