@@ -207,7 +207,7 @@ def kernel_names(precision, batched):
     wt = "float" if precision == "fp32" else "_Float16"
     nwq = os.environ.get("ER_NW_QKV", "6")
     nwq = nwq if nwq in ("3", "4") else "6"      # er_create's rule
-    if batched:     # B*16 >= 512: one streaming workgroup per (row, head); smaller batches keep the split round-1 kernel (er_api.hip, kind 1)
+    if batched:     # B*16 >= 256: one streaming workgroup per (row, head); smaller batches keep the split round-1 kernel (er_api.hip, kind 1)
         return {"attn_decode": [f"attn_stream_kernel<{wt}, 96, 2>", f"attn_decode_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
     if os.environ.get("ER_DECODE_V", "3") != "2":     # default: balanced chunks, merge fused into out_proj (no merge kernel)
         return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, {nwq}>"],

@@ -120,8 +120,8 @@ struct er_ctx {
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_grid_hs = 1;     // attention partial kernel (v2) dispatched heads-fastest: chunks beyond the current length exit last (ER_ATTN_GRID_HS=0: chunks fastest)
     bool out_valu = false;    // ER_OUT_VALU=1: batched out_proj on the VALU kernel (round-1 choice)
-    int attn_v_batched = 0;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 0 = auto (streaming when B*H >= 512, else split v1), 1 / 2 = split kernels + merge, 3 = one streaming workgroup per (row, head), no merge
-    bool stream_attn = false; // batched, D == 96 and (forced or B*H >= 512: two streaming workgroups per CU)
+    int attn_v_batched = 0;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 0 = auto (streaming when B*H >= 256, else split v1), 1 / 2 = split kernels + merge, 3 = one streaming workgroup per (row, head), no merge
+    bool stream_attn = false; // batched, D == 96 and (forced or B*H >= 256: at least one streaming workgroup per CU)
     int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     int decode_v = 3;         // single-row decode: 3 = balanced-chunk attention + merge fused into out_proj (one row, D = 96, 16 heads, Lcap <= 8192); ER_DECODE_V=2 = fixed 128-key chunks + merge kernel (also the fallback when the cache does not qualify)
     bool v3 = false;          // decode_v == 3 and the reserved cache qualifies
@@ -537,14 +537,15 @@ static int make_tiled_weights(er_ctx* c) {
 // ONE place for the selection rules (kv_alloc applies them, er_plan_decode reports them; pure host logic):
 //   batched     : B > 4 (or forced) - weights streamed once per pass of 32 rows on the matrix cores
 //   version 3   : one row, 16 heads of 96, hidden 1536, reserved cache <= 16 chunks x 512 keys; else version 2
-//   attention B>4: streaming kernel when forced or (auto and B * heads >= 512: two workgroups per CU), else split + merge
+//   attention B>4: streaming kernel when forced or (auto and B * heads >= 256: at least one workgroup per CU - at B = 16 it
+//                  ties the split kernel and saves the merge launch, at B = 8 it is 1.5x slower), else split + merge
 static void plan_decode(int decode_v, int attn_v_batched, bool force_batched, int batch, int H, int D, int hid, int Lcap,
                         er_decode_plan* p) {
     p->batched = (batch > 4 || force_batched) ? 1 : 0;
     p->attn_chunks = attn3_num_chunks(H);
     const bool v3 = decode_v == 3 && batch == 1 && !p->batched && D == 96 && H == 16 && hid == 1536 && attn3_fits(Lcap, H);
     p->decode_version = v3 ? 3 : 2;
-    const bool stream = p->batched && D == 96 && (attn_v_batched == 3 || (attn_v_batched == 0 && batch * H >= 512));
+    const bool stream = p->batched && D == 96 && (attn_v_batched == 3 || (attn_v_batched == 0 && batch * H >= 256));
     p->attn_kernel = !p->batched ? (v3 ? ER_ATTN_BALANCED : ER_ATTN_SPLIT2)
                                  : (stream ? ER_ATTN_STREAM : (attn_v_batched == 2 ? ER_ATTN_SPLIT2 : ER_ATTN_SPLIT1));
     p->merge_launch = (p->attn_kernel == ER_ATTN_SPLIT1 || p->attn_kernel == ER_ATTN_SPLIT2) ? 1 : 0;

@@ -275,9 +275,9 @@ def test_long_cache_falls_back_to_version2(gold_small):
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
 def test_streaming_batched_attention_ids(gold_small, monkeypatch, precision):
     """ER_ATTN_V_BATCHED=3 (one streaming workgroup per (row, head), no merge kernel) on an 18-row batch: rows of cloud 0
-    reproduce the golden ids (fp32) / the split kernels' ids (fp16; 18 x 16 < 512 pairs, so the default is the split kernel),
-    equal clouds give equal rows."""
+    reproduce the golden ids (fp32) / the split kernels' ids (fp16), equal clouds give equal rows."""
     batch = torch.cat([cloud(i % 3) for i in range(18)])
+    monkeypatch.setenv("ER_ATTN_V_BATCHED", "1")          # the split kernel + merge (the default below 16 rows)
     base = make_lmm(precision=precision)
     _, ref = base.generate(batch, 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
     monkeypatch.setenv("ER_ATTN_V_BATCHED", "3")

@@ -262,7 +262,8 @@ def test_decode_plan_batched_attention(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert _plan(32, 6051).attn_kernel == native.ER_ATTN_STREAM          # 512 (row, head) pairs: two workgroups per CU
     assert _plan(32, 18051).attn_kernel == native.ER_ATTN_STREAM         # configs[2]
-    p = _plan(31, 6051)
+    assert _plan(16, 6051).attn_kernel == native.ER_ATTN_STREAM          # 256 pairs: one workgroup per CU, still no merge launch
+    p = _plan(15, 6051)
     assert (p.batched, p.attn_kernel, p.merge_launch) == (1, native.ER_ATTN_SPLIT1, 1)
     assert _plan(5, 6051).attn_kernel == native.ER_ATTN_SPLIT1
     assert _plan(4, 6051).batched == 0
