@@ -17,6 +17,7 @@
 #include "er_common.h"
 #include "k_attn_decode.h"
 #include "k_outproj_merge.h"
+#include "k_flash_attn_f16s.h"
 #include "k_gemm.h"
 #include "k_gemv.h"
 #include "k_gemv_mfma.h"
@@ -116,6 +117,7 @@ struct er_ctx {
     int nw_qkv = 6, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV: 3, 4 or 6 - 6 waves x 1 row = 768 workgroups, 3 per CU; ER_NW_OUT: 3 or 4)
     bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
     bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
+    bool prefill_attn_f16s = false;   // STAGED, unmeasured (ER_PREFILL_ATTN_F16S=1): fast-mode prefix attention on the fp16 matrix cores with hi/lo-split q and p
     bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_grid_hs = 1;     // attention partial kernel (v2) dispatched heads-fastest: chunks beyond the current length exit last (ER_ATTN_GRID_HS=0: chunks fastest)
@@ -237,6 +239,7 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->flash_prefill = env_int("ER_PREFILL_ATTN", 2) != 1;
     c->debug_kv_flat = env_int("ER_DEBUG_KV_FLAT", 0) == 1;
     c->split_prefill = env_int("ER_PREFILL_GEMM", 2) != 1;
+    c->prefill_attn_f16s = env_int("ER_PREFILL_ATTN_F16S", 0) == 1;
     c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
     c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
     c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 1) == 0 ? 0 : 1;
@@ -1123,7 +1126,8 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
                 f.V = qkv + 2 * H; f.ldv = 3 * H; f.vs_b = f.qs_b; f.vs_h = D;
                 f.O = a; f.ldo = H; f.os_b = (long long)S * H; f.os_h = D;
                 f.N = S; f.M = S; f.sqrt_d = sqrtf((float)D); f.causal_off = 0;
-                HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
+                if (c->prefill_attn_f16s && D == 96) HIPRET(launch_flash_attn_f16s(f, D, true, NH, B, st));   // K / V in the scratch are fp16 values already
+                else HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
             } else {
                 ERCHK(ensure(c->p_sc, (size_t)NH * S * ldS));
                 for (int b = 0; b < B; ++b) {
@@ -1569,6 +1573,21 @@ extern "C" int er_k_flash_attn_f32(const float* q, const float* k, const float* 
     a.qs_h = a.ks_h = a.vs_h = a.os_h = D;
     a.sqrt_d = sqrtf((float)D); a.causal_off = M - N;
     HIPRET(launch_flash_attn_f32(a, D, causal != 0, H, B, (hipStream_t)stream));
+    return ER_OK;
+}
+
+extern "C" int er_k_flash_attn_f16s(const float* q, const float* k, const float* v, float* o, int B, int H, int N, int M, int causal,
+                                    void* stream) {
+    // STAGED (unmeasured): q/o [B, N, H*96], k/v [B, M, H*96] fp32 holding fp16-representable k / v values
+    if (causal && M < N) return fail(ER_ERR_INVALID, "er_k_flash_attn_f16s: causal needs M >= N");
+    constexpr int D = 96;
+    Flash32Args a{};
+    a.Q = q; a.K = k; a.V = v; a.O = o; a.N = N; a.M = M;
+    a.ldq = a.ldk = a.ldv = a.ldo = H * D;
+    a.qs_b = (long long)N * H * D; a.os_b = a.qs_b; a.ks_b = (long long)M * H * D; a.vs_b = a.ks_b;
+    a.qs_h = a.ks_h = a.vs_h = a.os_h = D;
+    a.sqrt_d = sqrtf((float)D); a.causal_off = M - N;
+    HIPRET(launch_flash_attn_f16s(a, D, causal != 0, H, B, (hipStream_t)stream));
     return ER_OK;
 }
 

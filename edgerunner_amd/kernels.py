@@ -110,6 +110,19 @@ def flash_attn_f32(q, k, v, heads, causal=False):
     return o
 
 
+
+def flash_attn_f16s(q, k, v, heads, causal=False):
+    """STAGED (round 3): the same attention for head_dim 96 on the fp16 matrix cores with hi/lo-split q and p; k / v must
+    hold fp16-representable values."""
+    lib = native.load_library()
+    B, N, HD = q.shape
+    assert HD // heads == 96
+    M = k.shape[1]
+    o = torch.empty_like(q)
+    native.check(lib.er_k_flash_attn_f16s(native.ptr(q), native.ptr(k), native.ptr(v), native.ptr(o), B, heads, N, M,
+                                          int(causal), _st()), "er_k_flash_attn_f16s")
+    return o
+
 def layernorm(x, w, b, eps=1e-5):
     lib = native.load_library()
     y = torch.empty_like(x)

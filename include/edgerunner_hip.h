@@ -274,6 +274,11 @@ int er_k_flash_attn_f16(const float* q_dev, const float* k_dev, const float* v_d
  * head_dim 96, and for the point encoder's cross-attention, head_dim 64).  q/o: [B, N, H*D], k/v: [B, M, H*D]. */
 int er_k_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int batch, int heads, int n, int m,
                         int head_dim, int causal, void* stream);
+/* STAGED for round 3 (unmeasured, not on the default path; env ER_PREFILL_ATTN_F16S=1 selects it for the fast-mode prefill):
+ * the same attention for head_dim 96 on the fp16 matrix cores with hi/lo-split q and p; k / v must hold
+ * fp16-representable values (the fast-mode prefill's scratch does) */
+int er_k_flash_attn_f16s(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch, int heads,
+                         int n_queries, int m_keys, int causal, void* stream);
 int er_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
                    int rows, int cols, float eps, void* stream);
 /* rows of scores[rows, ld]: softmax over the first n_valid(row) columns (causal: row+1+causal_offset), zeros after */

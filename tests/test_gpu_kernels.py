@@ -2,6 +2,7 @@
 plain torch reference of the same op (fp64 where cheap, fp32 otherwise) computed on
 the same device.  Tolerances are fp32 round-off: these are exact-fp32 kernels."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -167,6 +168,26 @@ def test_attn_decode_fp16_cache(D, lens, steps):
     for b, n in enumerate(lens):
         w = torch.softmax(q[b].view(H, 1, D).double() @ kc[b, :, :n].double().transpose(1, 2) / math.sqrt(D), dim=-1)
         close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"fp16-KV attn row {b} len {n}")
+
+
+@pytest.mark.skipif(os.environ.get("ER_TEST_STAGED") != "1", reason="staged for round 3: not on any default path, not yet run on a GPU")
+@pytest.mark.parametrize("B,H,N,M,causal", [(2, 16, 2050, 2050, True), (1, 3, 100, 333, False), (1, 2, 33, 33, True)])
+def test_flash_attn_f16s_staged(B, H, N, M, causal):
+    """Fast-mode prefill attention on the fp16 matrix cores with hi/lo-split q and p (ER_PREFILL_ATTN_F16S=1): fp16-valued
+    k / v, fp32 q; must agree with float64 to fp32 round-off like the fp32 kernel."""
+    from edgerunner_amd import kernels as K
+    D = 96
+    q = rnd(B, N, H * D, seed=80)
+    k, v = rnd(B, M, H * D, seed=81).half().float(), rnd(B, M, H * D, seed=82).half().float()
+    o = K.flash_attn_f16s(q, k, v, H, causal=causal)
+    qd, kd, vd = (t.double().view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    s = qd @ kd.transpose(2, 3) / math.sqrt(D)
+    if causal:
+        i = torch.arange(N, device=q.device)[:, None]
+        j = torch.arange(M, device=q.device)[None, :]
+        s = s.masked_fill(j > i + (M - N), float("-inf"))
+    ref = (torch.softmax(s, dim=-1) @ vd).transpose(1, 2).reshape(B, N, H * D)
+    close(o, ref, 3e-6, 1e-5, "split-fp16 flash attention")
 
 
 @pytest.mark.parametrize("half", [False, True])
