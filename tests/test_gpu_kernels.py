@@ -170,11 +170,11 @@ def test_attn_decode_fp16_cache(D, lens, steps):
         close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"fp16-KV attn row {b} len {n}")
 
 
-@pytest.mark.skipif(os.environ.get("ER_TEST_STAGED") != "1", reason="staged for round 3: not on any default path, not yet run on a GPU")
 @pytest.mark.parametrize("B,H,N,M,causal", [(2, 16, 2050, 2050, True), (1, 3, 100, 333, False), (1, 2, 33, 33, True)])
 def test_flash_attn_f16s_staged(B, H, N, M, causal):
-    """Fast-mode prefill attention on the fp16 matrix cores with hi/lo-split q and p (ER_PREFILL_ATTN_F16S=1): fp16-valued
-    k / v, fp32 q; must agree with float64 to fp32 round-off like the fp32 kernel."""
+    """Fast-mode prefill attention on the fp16 matrix cores with hi/lo-split q and p (staged for round 3: selected by
+    ER_PREFILL_ATTN_F16S=1 only, not timed yet): fp16-valued k / v, fp32 q; must agree with float64 to fp32 round-off like the
+    fp32 kernel (3 passed on the GPU at the end of round 2)."""
     from edgerunner_amd import kernels as K
     D = 96
     q = rnd(B, N, H * D, seed=80)
