@@ -2,6 +2,12 @@
 // all 24 layers with an XCD-hierarchical grid barrier per phase and the NEXT phase's weights prefetched into registers
 // BEFORE the barrier wait (the experiment VERDICT r1 asked to redo with the guide's barrier instead of the single-counter
 // probe).  (C) is (B) with the prefetch issued after the barrier, isolating what the prefetch buys.
+// (D) [added at the end of round 2, NOT YET RUN] replaces the barrier + acquire of (B) by a data-tagged all-gather: the 1536
+// floats the next phase reads travel as 8-byte {value, phase tag} granules, each written by ONE 64-bit relaxed agent-scope
+// atomic store (sc1 write-through) and swept by the sync wave of every CU with 64-bit relaxed agent-scope atomic loads until
+// all 1536 tags carry the phase number (MI355X_MICROARCH.md price list: handoff / allgather rows), then handed to the compute
+// waves through LDS.  Two granule buffers by phase parity: a producer of phase p+2 cannot run before every CU has consumed
+// phase p.  Spins are bounded; a give-up is reported, never a hang.
 //
 // The layer keeps the real byte volumes and the real all-to-all dependency structure of the B = 1 fp32 decode layer
 // (every phase needs the WHOLE output vector of the previous one), with simplified arithmetic: five GEMVs over rows of
@@ -20,6 +26,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) float gf32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr int K = 1536, NPH = 5, NL = 24, XLEN = 8192;
@@ -95,9 +102,15 @@ constexpr int PW = 16, CW = PW - 1, PT = PW * 64, RMAX = 3;   // waves per workg
 // grid = one workgroup per CU (the 100 KB dynamic LDS request forces one per CU).  Wave PW-1 is the "sync" wave: it
 // publishes the workgroup's outputs (write-through sc1 stores), drains them, runs the grid barrier and the acquire; the
 // 15 compute waves meanwhile have the next phase's weight rows in flight and park on the workgroup barrier.
-template <bool PREFETCH>
-__global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict__ Wall, float* xbuf0, float* xbuf1, BarState* s, int layers) {
-    extern __shared__ float ylds[];            // [64] outputs of this workgroup in the current phase
+// MODE 0: barrier, prefetch before it (B); 1: barrier, prefetch after it (C); 2: tagged all-gather, prefetch before it (D)
+constexpr int GRAN_N = K;                      // granules per phase: the 1536 floats the next phase reads
+template <int MODE>
+__global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict__ Wall, float* xbuf0, float* xbuf1, BarState* s, int layers,
+                                                        unsigned long long* gran0, unsigned long long* gran1) {
+    constexpr bool PREFETCH = MODE != 1;
+    constexpr bool GATHER = MODE == 2;
+    extern __shared__ float ylds[];            // [64] outputs of this workgroup in the current phase; [256 ..] the gathered x (MODE 2)
+    float* xs = ylds + 256;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int cu = blockIdx.x, ncu = gridDim.x;
     const unsigned xcc = xcc_id();
@@ -135,6 +148,10 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
     };
     const int total = layers * NPH;
     if (wid < CW) issue(0);
+    if (GATHER) {                              // phase 0 reads the host-written vector
+        for (int i = threadIdx.x; i < K; i += PT) xs[i] = xbuf0[i];
+        __syncthreads();
+    }
     unsigned epoch = 0;
     for (int gp = 0; gp < total; ++gp) {
         const int p = gp % NPH;
@@ -145,7 +162,7 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
             if (!PREFETCH && gp > 0) issue(gp);
             f32x4 x[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) x[j] = reinterpret_cast<const f32x4*>(xin)[j * 64 + lane];
+            for (int j = 0; j < 6; ++j) x[j] = GATHER ? reinterpret_cast<const f32x4*>(xs)[j * 64 + lane] : reinterpret_cast<const f32x4*>(xin)[j * 64 + lane];
             const int nloc = (N - cu + ncu - 1) / ncu;
 #pragma unroll
             for (int i = 0; i < RMAX; ++i) {
@@ -158,7 +175,45 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
             if (PREFETCH && gp + 1 < total) issue(gp + 1);     // in flight across the grid barrier
         }
         __syncthreads();                                        // ylds complete
-        if (wid == CW) {
+        if (wid == CW && GATHER) {
+            // (D) publish: every row to yout (the final check reads it), the rows the next phase reads also as tagged granules
+            unsigned long long* gw = ((gp + 1) & 1) ? gran1 : gran0;
+            if (lane < 48) {
+                const int row = cu + ncu * lane;
+                if (row < N) {
+                    const float v = ylds[lane];
+                    __hip_atomic_store((gf32*)(yout + row), v, RLX_AGENT);
+                    if (row < GRAN_N && gp + 1 < total)
+                        __hip_atomic_store((gu64*)(gw + row), ((unsigned long long)(unsigned)(gp + 1) << 32) | (unsigned long long)__float_as_uint(v), RLX_AGENT);
+                }
+            }
+            if (gp + 1 < total) {
+                // gather: lane l owns granules l, l + 64, ... (24 per lane); re-read only what has not arrived yet
+                constexpr int PER = GRAN_N / 64;
+                unsigned pending = (1u << PER) - 1u;
+                unsigned spins = 0;
+                bool gave_up = false;
+                while (__any(pending != 0u)) {
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) {
+                        if (pending & (1u << j)) {
+                            const unsigned long long g = __hip_atomic_load((gu64*)(gw + lane + 64 * j), RLX_AGENT);
+                            if ((unsigned)(g >> 32) == (unsigned)(gp + 1)) {
+                                xs[lane + 64 * j] = __uint_as_float((unsigned)g);
+                                pending &= ~(1u << j);
+                            }
+                        }
+                    }
+                    if (++spins > SPIN_LIMIT / 64 || __hip_atomic_load((gu32*)&s->error[0], RLX_AGENT) != 0) {
+                        __hip_atomic_store((gu32*)&s->error[0], 1u, RLX_AGENT);
+                        gave_up = true;
+                        break;
+                    }
+                    if (__any(pending != 0u)) __builtin_amdgcn_s_sleep(1);
+                }
+                (void)gave_up;
+            }
+        } else if (wid == CW) {
             // publish this workgroup's rows (write-through), drain, grid barrier, acquire
             if (lane < 48) {
                 const int row = cu + ncu * lane;
@@ -263,18 +318,26 @@ int main(int argc, char** argv) {
 
     // ---- (B)/(C) persistent
     const size_t lds = 100 * 1024;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int variant = 0; variant < 2; ++variant) {
-        const bool prefetch = variant == 0;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    unsigned long long *g0, *g1;
+    CHECK(hipMalloc(&g0, GRAN_N * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&g1, GRAN_N * sizeof(unsigned long long)));
+    const int nvariants = (argc > 1 && atoi(argv[1]) == 2) ? 2 : 3;      // argv[1] = 2: skip the tagged-gather variant
+    for (int variant = 0; variant < nvariants; ++variant) {
+        const bool prefetch = variant != 1;
         float best = 1e9f;
         bool ok = true, timeout = false;
         for (int r = 0; r < 6; ++r) {
             reset_x();
             CHECK(hipMemsetAsync(bs, 0, sizeof(BarState), st));
+            CHECK(hipMemsetAsync(g0, 0, GRAN_N * sizeof(unsigned long long), st));     // tag 0 never matches a phase number (1..)
+            CHECK(hipMemsetAsync(g1, 0, GRAN_N * sizeof(unsigned long long), st));
             CHECK(hipEventRecord(e0, st));
-            if (prefetch) hipLaunchKernelGGL(persistent_kernel<true>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL);
-            else hipLaunchKernelGGL(persistent_kernel<false>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL);
+            if (variant == 0) hipLaunchKernelGGL(persistent_kernel<0>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
+            else if (variant == 1) hipLaunchKernelGGL(persistent_kernel<1>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
+            else hipLaunchKernelGGL(persistent_kernel<2>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
             CHECK(hipGetLastError());
             CHECK(hipEventRecord(e1, st));
             CHECK(hipStreamSynchronize(st));
@@ -289,9 +352,9 @@ int main(int argc, char** argv) {
             if (timeout) break;
         }
         const double us = best * 1000.0 / NL;
-        printf("(%c) persistent, xcd barrier, prefetch %-6s: %7.2f us per layer  (%.2f TB/s)  result %s%s\n", prefetch ? 'B' : 'C',
-               prefetch ? "before" : "after", us, per_layer * 4 / us / 1e6, ok ? "bit-identical to (A)" : "DIFFERS from (A)",
-               timeout ? "  [SPIN TIMEOUT]" : "");
+        printf("(%c) persistent, %s, prefetch %-6s: %7.2f us per layer  (%.2f TB/s)  result %s%s\n", "BCD"[variant],
+               variant == 2 ? "tagged all-gather" : "xcd barrier", prefetch ? "before" : "after", us, per_layer * 4 / us / 1e6,
+               ok ? "bit-identical to (A)" : "DIFFERS from (A)", timeout ? "  [SPIN TIMEOUT]" : "");
     }
     return 0;
 }
