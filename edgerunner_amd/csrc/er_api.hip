@@ -114,6 +114,7 @@ struct er_ctx {
     float* skpart = nullptr;  // split-K partials of the batched fc2
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
     int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
+    int nw_fc1 = 4;
     int nw_qkv = 6, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV: 3, 4 or 6 - 6 waves x 1 row = 768 workgroups, 3 per CU; ER_NW_OUT: 3 or 4)
     bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
     bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
@@ -228,8 +229,11 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     c->use_graph = !(ng && ng[0] == '1');
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
     c->rw_qkv = env_int("ER_RW_QKV", 1);
-    c->nw_qkv = env_int("ER_NW_QKV", 6);
-    if (c->nw_qkv != 3 && c->nw_qkv != 4) c->nw_qkv = 6;
+    // one fat workgroup per CU (qkv 9 waves x 2 rows, fc1 12 waves x 2 rows) pays with fp16 weights only: the LayerNorm prologue and
+    // its 18 KB of x / affine reads are then once per CU instead of three times (profiles/r03_fat_workgroups.log: fp16 +2.7 %, fp32 +-0)
+    c->nw_qkv = env_int("ER_NW_QKV", fast ? 9 : 6);
+    if (c->nw_qkv != 3 && c->nw_qkv != 4 && c->nw_qkv != 9) c->nw_qkv = 6;
+    c->nw_fc1 = env_int("ER_NW_FC1", fast ? 12 : 4) == 12 ? 12 : 4;
     c->nw_out = env_int("ER_NW_OUT", 3) == 4 ? 4 : 3;
     c->rw_fc1 = env_int("ER_RW_FC1", 2);
     c->rw_fc2 = env_int("ER_RW_FC2", 2);
@@ -683,6 +687,8 @@ static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st, int 
             return gemv_groups<WT, KS, 2, PRO, EPI, 3>(a, B, K, st);
         }
         if (nw == 6) return gemv_groups<WT, KS, 1, PRO, EPI, 6>(a, B, K, st);     // 6 waves x 1 row: 4608 qkv rows = 768 workgroups
+        if (nw == 9) return gemv_groups<WT, KS, 2, PRO, EPI, 9>(a, B, K, st);     // 9 waves x 2 rows: 4608 qkv rows = 256 workgroups, one per CU
+        if (nw == 12) return gemv_groups<WT, KS, 2, PRO, EPI, 12>(a, B, K, st);   // 12 waves x 2 rows: 6144 fc1 rows = 256 workgroups, one per CU
     }
     switch (rw) {
         case 1: return gemv_groups<WT, KS, 1, PRO, EPI>(a, B, K, st);
@@ -836,7 +842,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 if (!c->batched_valu) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, c->skpart, st); }   // 192 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_RELU>(a, B, H, st);   // 6144 rows = 256 workgroups x 24
             }
-            return gemv_rw<WT, 1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st);
+            return gemv_rw<WT, 1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st, c->nw_fc1);
         }
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];

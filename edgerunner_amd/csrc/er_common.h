@@ -63,6 +63,13 @@ __device__ __forceinline__ float row_ror(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
 }
 
+// DPP row broadcast (GFX9 wave reductions): CTRL 0x142 = row_bcast:15 (lane 15 of every row -> all lanes of the NEXT row),
+// 0x143 = row_bcast:31 (lane 31 -> all lanes of rows 2 and 3); lanes of rows outside ROW_MASK get `fill`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float row_bcast(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b, float acc) {
     acc = fmaf(a.x, b.x, acc);
     acc = fmaf(a.y, b.y, acc);

@@ -18,6 +18,11 @@
 #pragma once
 #include "er_common.h"
 
+// timeline hooks of scripts/probes/attn_timeline_probe.hip (expand to nothing in the library build)
+#ifndef ER_TP
+#define ER_TP(i)
+#endif
+
 namespace er {
 
 struct AttnDecArgs {
@@ -431,9 +436,11 @@ __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
 // key group i*NW + w is step-major, so the number of active steps is uniform over the workgroup and is dispatched OUTSIDE the
 // unrolled load block (a per-load condition would make hipcc branch around - and wait for - every load).
 // Partials: o rows [B][H][NCH][D] (16-byte aligned float4 columns) and {m, l} pairs [B][H][NCH][2].
+constexpr int A3_LD = 97;     // row stride of the wave partials in LDS (D + 1: lanes that read a column down the rows hit 32 different banks)
+
 template <typename KT, int D, int NS, int NW>
 __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, const KT* vb, const float* qp, int k0, int k1,
-                                           float* ored, float* wm, float* wl, float* gsum, float* gl, float* po, float* pml) {
+                                           float* ored, float* wm, float* wl, float* po, float* pml) {
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
     constexpr int NV = D / (EPL * LPK);
     constexpr int KPW = 64 / LPK;
@@ -465,6 +472,7 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
         for (int j = 0; j < NV; ++j) vreg[i][j] = __builtin_nontemporal_load(vr + j * LPK + p);
     }
     __builtin_amdgcn_sched_barrier(0);
+    ER_TP(2);
 
     float sc[NS];
     float mloc = -INFINITY;
@@ -484,6 +492,7 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
         mloc = fmaxf(mloc, sc[i]);
     }
     const float m = wave_max(mloc);           // -inf when the wave holds no valid key
+    ER_TP(3);
     float pw[NS];
     float lloc = 0.f;
 #pragma unroll
@@ -506,6 +515,7 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
 #pragma unroll
             for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
         }
+    ER_TP(4);
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -514,7 +524,7 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
             if (LPK == 4) o[j][e] += row_ror<4>(o[j][e]);
         }
     if ((lane & 15) < LPK) {
-        float* dst = ored + (wid * 4 + (lane >> 4)) * D;
+        float* dst = ored + (wid * 4 + (lane >> 4)) * A3_LD;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -522,43 +532,55 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
     }
     if (lane == 0) { wm[wid] = m; wl[wid] = l; }
     __syncthreads();
-    // two-level merge of the NW wave partials: NW/2 groups of D threads weigh two waves each (one expf per wave instead of
-    // NW per thread), then D threads add the NW/2 group sums - 96 threads walking all 16 waves cost ~0.5 us of tail
-    constexpr int NG = NW / 2;
-    float M = wm[0];
+    ER_TP(5);
+    // ONE barrier: the 4 * NW = 64 row partials {wave k, row r of 16 lanes} of a column meet in the 64 lanes of ONE wave - wave w
+    // owns columns [w * D/NW, (w + 1) * D/NW), lane = 4k + r reads them from row (k, r) (row stride A3_LD = D + 1 floats: conflict
+    // free), weighs them with exp(m_k - M) and the wave adds them up: four row_ror steps inside each row of 16 lanes, then the four
+    // row totals through readlane in a fixed order.  (Round 2 used two barriers and two LDS round trips: 0.75 us of tail per launch
+    // in profiles/r03_attn_timeline.log, against ~0.25 us here.)
+    constexpr int CPW = D / NW;                // columns per wave
+    const int k = lane >> 2;
+    const float mk = wm[k], lk = wl[k];
+    const float* src = ored + lane * A3_LD + wid * CPW;
+    float acc[CPW + 1];
 #pragma unroll
-    for (int k = 1; k < NW; ++k) M = fmaxf(M, wm[k]);        // finite: the chunk holds at least one key
-    const int grp = tid / D, d = tid - grp * D;
-    if (grp < NG) {
-        float ov = 0.f, lv = 0.f;
+    for (int i = 0; i < CPW; ++i) acc[i] = src[i];
+    // maximum over the 16 waves: two rotations inside each row of 16 lanes (4 waves per row), then the classic row_bcast steps
+    // (row 1 <- row 0, row 3 <- row 2, rows 2..3 <- row 1), the result read back from lane 63
+    float mx = fmaxf(mk, row_ror<4>(mk));
+    mx = fmaxf(mx, row_ror<8>(mx));
+    mx = fmaxf(mx, row_bcast<0x142, 0xa>(mx, -INFINITY));
+    mx = fmaxf(mx, row_bcast<0x143, 0xc>(mx, -INFINITY));
+    const float M = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 63));     // finite: the chunk holds at least one key
+    const float w = (mk == -INFINITY) ? 0.f : expf(mk - M);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int k = 2 * grp + kk;
-            const float w = (wm[k] == -INFINITY) ? 0.f : expf(wm[k] - M);
-            const float* src = ored + k * 4 * D + d;
-            ov = fmaf((src[0] + src[D]) + (src[2 * D] + src[3 * D]), w, ov);
-            lv = fmaf(wl[k], w, lv);
-        }
-        gsum[grp * D + d] = ov;
-        if (d == 0) gl[grp] = lv;
+    for (int i = 0; i < CPW; ++i) acc[i] *= w;
+    acc[CPW] = (lane & 3) == 0 ? lk * w : 0.f;
+#pragma unroll
+    for (int i = 0; i <= CPW; ++i) {           // CPW + 1 independent chains: the totals end up in lanes 48..63
+        float v = acc[i];
+        v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+        v += row_bcast<0x142, 0xa>(v, 0.f);
+        v += row_bcast<0x143, 0xc>(v, 0.f);
+        acc[i] = v;
     }
-    __syncthreads();
-    if (tid < D) {
-        float ov = 0.f, lv = 0.f;
+    if (lane >= 48 && lane < 48 + CPW) {
+        float v = acc[0];
 #pragma unroll
-        for (int q = 0; q < NG; ++q) { ov += gsum[q * D + tid]; lv += gl[q]; }
-        po[tid] = ov;
-        if (tid == 0) { pml[0] = M; pml[1] = lv; }
+        for (int i = 1; i < CPW; ++i) v = (lane == 48 + i) ? acc[i] : v;
+        po[wid * CPW + lane - 48] = v;
     }
+    if (tid == 63) { pml[0] = M; pml[1] = acc[CPW]; }
+    ER_TP(7);
 }
 
 template <typename KT, int D, int STEPS, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(AttnDecArgs a) {
     constexpr int KPW = 64 / KVec<KT>::LPK;
-    static_assert(NW % 2 == 0 && (NW / 2) * D <= 64 * NW, "two-level merge: NW/2 groups of D threads");
-    __shared__ __attribute__((aligned(16))) float ored[NW * 4 * D];
-    __shared__ float gsum[(NW / 2) * D];
-    __shared__ float wm[NW], wl[NW], gl[NW / 2];
+    static_assert(NW == 16 && D % NW == 0 && D + 1 == A3_LD, "wave merge: the 4 * NW row partials of a column fill the 64 lanes of one wave");
+    __shared__ __attribute__((aligned(16))) float ored[NW * 4 * A3_LD];
+    __shared__ float wm[NW], wl[NW];
+    ER_TP(0);
     const int h = blockIdx.x, c = blockIdx.y, b = blockIdx.z, nch = gridDim.y;
     const int len = attn_len(a, b);
     const int clen = (len + nch - 1) / nch;                 // <= STEPS * NW * KPW (the launcher checks l_cap)
@@ -575,10 +597,11 @@ __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(AttnDecArgs a) {
     const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
     const float* qp = a.q + (long long)b * a.hidden + h * D;
     const int nsteps = (k1 - k0 + NW * KPW - 1) / (NW * KPW);      // workgroup-uniform
-    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
-    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
-    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
-    else attn3_body<KT, D, 1, NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, gsum, gl, po, pml);
+    ER_TP(1);
+    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    else attn3_body<KT, D, 1, NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
 }
 
 constexpr int ATTN3_NW = 16;                   // waves per workgroup of the balanced kernel

@@ -78,6 +78,7 @@ struct BarState {
     unsigned top[32];
     unsigned start[32];
     unsigned error[32];
+    unsigned shard[8 * 32];    // (F) flat arrival counters, one 128-byte line per shard (cu % 8)
 };
 constexpr unsigned SPIN_LIMIT = 4000000u;
 
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
                                                         unsigned long long* gran0, unsigned long long* gran1) {
     constexpr bool PREFETCH = MODE != 1;
     constexpr bool GATHER = MODE == 2;
+    constexpr bool FLAT = MODE == 3;           // (F): sharded arrival counters polled by every CU, x read with sc1 loads - no fence, no barrier tree
     extern __shared__ float ylds[];            // [64] outputs of this workgroup in the current phase; [256 ..] the gathered x (MODE 2)
     float* xs = ylds + 256;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
     };
     const int total = layers * NPH;
     if (wid < CW) issue(0);
-    if (GATHER) {                              // phase 0 reads the host-written vector
+    if (GATHER || FLAT) {                      // phase 0 reads the host-written vector
         for (int i = threadIdx.x; i < K; i += PT) xs[i] = xbuf0[i];
         __syncthreads();
     }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
             if (!PREFETCH && gp > 0) issue(gp);
             f32x4 x[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) x[j] = GATHER ? reinterpret_cast<const f32x4*>(xs)[j * 64 + lane] : reinterpret_cast<const f32x4*>(xin)[j * 64 + lane];
+            for (int j = 0; j < 6; ++j) x[j] = (GATHER || FLAT) ? reinterpret_cast<const f32x4*>(xs)[j * 64 + lane] : reinterpret_cast<const f32x4*>(xin)[j * 64 + lane];
             const int nloc = (N - cu + ncu - 1) / ncu;
 #pragma unroll
             for (int i = 0; i < RMAX; ++i) {
@@ -212,6 +214,43 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
                     if (__any(pending != 0u)) __builtin_amdgcn_s_sleep(1);
                 }
                 (void)gave_up;
+            }
+        } else if (wid == CW && FLAT) {
+            // (F) publish write-through, drain, ONE arrival on shard cu % 8, poll the 8 shards, fetch x past L1 (sc1) into LDS
+            if (lane < 48) {
+                const int row = cu + ncu * lane;
+                if (row < N) __hip_atomic_store((gf32*)(yout + row), ylds[lane], RLX_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (gp + 1 < total) {
+                if (lane == 0) __hip_atomic_fetch_add((gu32*)&s->shard[(cu & 7) * 32], 1u, RLX_AGENT);
+                const unsigned want = (unsigned)(gp + 1) * (unsigned)((ncu + 7 - (lane & 7)) / 8);   // arrivals of shard (lane & 7) so far
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned c = __hip_atomic_load((gu32*)&s->shard[(lane & 7) * 32], RLX_AGENT);
+                    if (__all(c >= want)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT / 16 || __hip_atomic_load((gu32*)&s->error[0], RLX_AGENT) != 0) {
+                        __hip_atomic_store((gu32*)&s->error[0], 1u, RLX_AGENT);
+                        break;
+                    }
+                }
+                f32x4 t[6];
+                const float* p0 = yout + lane * 4;
+                const float* p1 = p0 + 3 * 256;
+                asm volatile(
+                    "global_load_dwordx4 %0, %6, off sc1\n\t"
+                    "global_load_dwordx4 %1, %6, off offset:1024 sc1\n\t"
+                    "global_load_dwordx4 %2, %6, off offset:2048 sc1\n\t"
+                    "global_load_dwordx4 %3, %7, off sc1\n\t"
+                    "global_load_dwordx4 %4, %7, off offset:1024 sc1\n\t"
+                    "global_load_dwordx4 %5, %7, off offset:2048 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5])
+                    : "v"(p0), "v"(p1)
+                    : "memory");
+#pragma unroll
+                for (int j = 0; j < 6; ++j) reinterpret_cast<f32x4*>(xs)[j * 64 + lane] = t[j];
             }
         } else if (wid == CW) {
             // publish this workgroup's rows (write-through), drain, grid barrier, acquire
@@ -321,11 +360,13 @@ int main(int argc, char** argv) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     unsigned long long *g0, *g1;
     CHECK(hipMalloc(&g0, GRAN_N * sizeof(unsigned long long)));
     CHECK(hipMalloc(&g1, GRAN_N * sizeof(unsigned long long)));
-    const int nvariants = (argc > 1 && atoi(argv[1]) == 2) ? 2 : 3;      // argv[1] = 2: skip the tagged-gather variant
-    for (int variant = 0; variant < nvariants; ++variant) {
+    const int vmask = argc > 1 ? atoi(argv[1]) : 15;      // bit v selects variant v: 1 = (B), 2 = (C), 4 = (D), 8 = (F)
+    for (int variant = 0; variant < 4; ++variant) {
+        if (!(vmask & (1 << variant))) continue;
         const bool prefetch = variant != 1;
         float best = 1e9f;
         bool ok = true, timeout = false;
@@ -337,7 +378,8 @@ int main(int argc, char** argv) {
             CHECK(hipEventRecord(e0, st));
             if (variant == 0) hipLaunchKernelGGL(persistent_kernel<0>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
             else if (variant == 1) hipLaunchKernelGGL(persistent_kernel<1>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
-            else hipLaunchKernelGGL(persistent_kernel<2>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
+            else if (variant == 2) hipLaunchKernelGGL(persistent_kernel<2>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
+            else hipLaunchKernelGGL(persistent_kernel<3>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
             CHECK(hipGetLastError());
             CHECK(hipEventRecord(e1, st));
             CHECK(hipStreamSynchronize(st));
@@ -352,8 +394,8 @@ int main(int argc, char** argv) {
             if (timeout) break;
         }
         const double us = best * 1000.0 / NL;
-        printf("(%c) persistent, %s, prefetch %-6s: %7.2f us per layer  (%.2f TB/s)  result %s%s\n", "BCD"[variant],
-               variant == 2 ? "tagged all-gather" : "xcd barrier", prefetch ? "before" : "after", us, per_layer * 4 / us / 1e6,
+        printf("(%c) persistent, %s, prefetch %-6s: %7.2f us per layer  (%.2f TB/s)  result %s%s\n", "BCDF"[variant],
+               variant == 2 ? "tagged all-gather" : (variant == 3 ? "flat sharded counters + sc1 reads" : "xcd barrier"), prefetch ? "before" : "after", us, per_layer * 4 / us / 1e6,
                ok ? "bit-identical to (A)" : "DIFFERS from (A)", timeout ? "  [SPIN TIMEOUT]" : "");
     }
     return 0;
