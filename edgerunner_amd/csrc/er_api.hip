@@ -113,19 +113,15 @@ struct er_ctx {
     bool batched_valu = false;   // ER_BATCHED_VALU=1: the older VALU kernels (one pass per 16 rows), kept for A/B runs
     float* skpart = nullptr;  // split-K partials of the batched fc2
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
-    int rw_qkv = 1, rw_fc1 = 2, rw_fc2 = 2, rw_out = 1, attn_steps = 4;   // tuning knobs (env ER_RW_*, ER_ATTN_STEPS)
-    int nw_fc1 = 4;
-    int nw_qkv = 6, nw_out = 3;    // waves per workgroup of the qkv / out_proj GEMVs (env ER_NW_QKV: 3, 4 or 6 - 6 waves x 1 row = 768 workgroups, 3 per CU; ER_NW_OUT: 3 or 4)
-    bool flash_prefill = true;   // ER_PREFILL_ATTN=1: the round-1 materialised scores -> softmax -> P.V path (A/B runs)
-    bool split_prefill = true;   // fast mode: prefill Linears on the fp16 matrix cores with hi/lo-split activations (ER_PREFILL_GEMM=1: fp32 GEMMs)
+    // waves per workgroup of the qkv / fc1 GEMVs (env ER_NW_QKV: 4, 6 or 9; ER_NW_FC1: 4 or 12).  Exact mode: qkv 6 waves x 1 row
+    // = 768 workgroups (3 per CU), fc1 4 waves x 2 rows = 768; fast mode: one fat workgroup per CU (9 / 12 waves x 2 rows).  The other
+    // shapes are fixed (out_proj 3 waves x 1 row, fc2 4 K-slices x 2 rows, 128-key chunks for the fixed-chunk attention): their
+    // round-1/2 knobs (ER_RW_*, ER_NW_OUT, ER_ATTN_STEPS, ER_ATTN_V, ER_COMBINE_V, ER_ATTN_GRID_HS, ER_OUT_VALU) are settled and gone
+    int nw_qkv = 6, nw_fc1 = 4;
     bool prefill_attn_f16s = false;   // STAGED, unmeasured (ER_PREFILL_ATTN_F16S=1): fast-mode prefix attention on the fp16 matrix cores with hi/lo-split q and p
-    bool debug_kv_flat = false;  // ER_DEBUG_KV_FLAT=1: timing probe, the qkv epilogue writes k/v to a scratch row (RESULTS ARE WRONG)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
-    int attn_grid_hs = 1;     // attention partial kernel (v2) dispatched heads-fastest: chunks beyond the current length exit last (ER_ATTN_GRID_HS=0: chunks fastest)
-    bool out_valu = false;    // ER_OUT_VALU=1: batched out_proj on the VALU kernel (round-1 choice)
-    int attn_v_batched = 0;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 0 = auto (streaming when B*H >= 256, else split v1), 1 / 2 = split kernels + merge, 3 = one streaming workgroup per (row, head), no merge
+    int attn_v_batched = 0;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 0 = auto (streaming when B*H >= 256, else split + merge), 1 = split kernel + merge, 3 = one streaming workgroup per (row, head), no merge
     bool stream_attn = false; // batched, D == 96 and (forced or B*H >= 256: at least one streaming workgroup per CU)
-    int attn_v = 2, combine_v = 2;   // kernel versions (env ER_ATTN_V / ER_COMBINE_V = 1 selects the round-1 kernels for A/B runs)
     int decode_v = 3;         // single-row decode: 3 = balanced-chunk attention + merge fused into out_proj (one row, D = 96, 16 heads, Lcap <= 8192); ER_DECODE_V=2 = fixed 128-key chunks + merge kernel (also the fallback when the cache does not qualify)
     bool v3 = false;          // decode_v == 3 and the reserved cache qualifies
     int nch3 = 0;             // chunks per head of the balanced attention kernel
@@ -228,28 +224,14 @@ extern "C" int er_create(const er_config* cfg, int device, er_ctx** out) {
     const char* ng = getenv("ER_NO_GRAPH");
     c->use_graph = !(ng && ng[0] == '1');
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
-    c->rw_qkv = env_int("ER_RW_QKV", 1);
     // one fat workgroup per CU (qkv 9 waves x 2 rows, fc1 12 waves x 2 rows) pays with fp16 weights only: the LayerNorm prologue and
     // its 18 KB of x / affine reads are then once per CU instead of three times (profiles/r03_fat_workgroups.log: fp16 +2.7 %, fp32 +-0)
     c->nw_qkv = env_int("ER_NW_QKV", fast ? 9 : 6);
-    if (c->nw_qkv != 3 && c->nw_qkv != 4 && c->nw_qkv != 9) c->nw_qkv = 6;
+    if (c->nw_qkv != 4 && c->nw_qkv != 9) c->nw_qkv = 6;
     c->nw_fc1 = env_int("ER_NW_FC1", fast ? 12 : 4) == 12 ? 12 : 4;
-    c->nw_out = env_int("ER_NW_OUT", 3) == 4 ? 4 : 3;
-    c->rw_fc1 = env_int("ER_RW_FC1", 2);
-    c->rw_fc2 = env_int("ER_RW_FC2", 2);
-    c->rw_out = env_int("ER_RW_OUT", 1);
-    c->attn_steps = env_int("ER_ATTN_STEPS", ATTN_STEPS_DEFAULT);
-    if (c->attn_steps != 2 && c->attn_steps != 8) c->attn_steps = 4;
-    c->flash_prefill = env_int("ER_PREFILL_ATTN", 2) != 1;
-    c->debug_kv_flat = env_int("ER_DEBUG_KV_FLAT", 0) == 1;
-    c->split_prefill = env_int("ER_PREFILL_GEMM", 2) != 1;
     c->prefill_attn_f16s = env_int("ER_PREFILL_ATTN_F16S", 0) == 1;
-    c->attn_v = env_int("ER_ATTN_V", 2) == 1 ? 1 : 2;
-    c->combine_v = env_int("ER_COMBINE_V", 2) == 1 ? 1 : 2;
-    c->attn_grid_hs = env_int("ER_ATTN_GRID_HS", 1) == 0 ? 0 : 1;
     c->attn_v_batched = env_int("ER_ATTN_V_BATCHED", 0);
-    if (c->attn_v_batched < 0 || c->attn_v_batched > 3) c->attn_v_batched = 0;
-    c->out_valu = env_int("ER_OUT_VALU", 0) == 1;
+    if (c->attn_v_batched != 1 && c->attn_v_batched != 3) c->attn_v_batched = 0;
     c->decode_v = env_int("ER_DECODE_V", 3) == 2 ? 2 : 3;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault));
     HIPCHK(hipEventCreate(&c->ev0));
@@ -554,7 +536,7 @@ static void plan_decode(int decode_v, int attn_v_batched, bool force_batched, in
     p->decode_version = v3 ? 3 : 2;
     const bool stream = p->batched && D == 96 && (attn_v_batched == 3 || (attn_v_batched == 0 && batch * H >= 256));
     p->attn_kernel = !p->batched ? (v3 ? ER_ATTN_BALANCED : ER_ATTN_SPLIT2)
-                                 : (stream ? ER_ATTN_STREAM : (attn_v_batched == 2 ? ER_ATTN_SPLIT2 : ER_ATTN_SPLIT1));
+                                 : (stream ? ER_ATTN_STREAM : ER_ATTN_SPLIT1);
     p->merge_launch = (p->attn_kernel == ER_ATTN_SPLIT1 || p->attn_kernel == ER_ATTN_SPLIT2) ? 1 : 0;
     p->launches_per_layer = p->batched ? 0 : 5 + p->merge_launch;       // qkv, attention, (merge,) out_proj, fc1, fc2
 }
@@ -565,9 +547,19 @@ extern "C" int er_plan_decode(int batch, int heads, int head_dim, int hidden, in
     if (!out || batch <= 0 || heads <= 0 || head_dim <= 0 || l_cap <= 0) return fail(ER_ERR_INVALID, "er_plan_decode: bad argument");
     int dv = env_int_("ER_DECODE_V", 3) == 2 ? 2 : 3;
     int avb = env_int_("ER_ATTN_V_BATCHED", 0);
-    if (avb < 0 || avb > 3) avb = 0;
+    if (avb != 1 && avb != 3) avb = 0;
     const char* fb = getenv("ER_FORCE_BATCHED");
     plan_decode(dv, avb, fb && fb[0] == '1', batch, heads, head_dim, hidden, (l_cap + 31) / 32 * 32, out);
+    return ER_OK;
+}
+
+// the plan of a LIVE context: its knobs were fixed at er_create and its cache by the last er_kv_reserve (er_plan_decode above
+// evaluates the same rules for hypothetical shapes with the environment as it is at call time)
+extern "C" int er_ctx_plan(er_ctx* c, er_decode_plan* out) {
+    if (!c || !out) return fail(ER_ERR_INVALID, "er_ctx_plan: null argument");
+    if (c->B <= 0) return fail(ER_ERR_INVALID, "er_ctx_plan: no cache reserved (call er_kv_reserve)");
+    plan_decode(c->decode_v, c->attn_v_batched, /*force_batched=*/c->batched && c->B <= 4, c->B, c->cfg.num_heads, c->D,
+                c->cfg.hidden_dim, c->Lcap, out);
     return ER_OK;
 }
 
@@ -604,7 +596,7 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     HIPCHK(hipMalloc(&c->kc, kv_elems * c->kv_esz));
     HIPCHK(hipMalloc(&c->vc, kv_elems * c->kv_esz));
     // decode attention: one workgroup per (row, head, chunk of 32*steps keys)
-    const int S = attn_num_chunks(Lcap, attn_chunk(c->attn_steps, c->fast));
+    const int S = attn_num_chunks(Lcap, attn_chunk(ATTN_STEPS_DEFAULT, c->fast));
     c->S_splits = S;
     const size_t b = (size_t)batch;
     HIPCHK(hipMalloc(&c->ypre, b * hid * 4));
@@ -678,23 +670,15 @@ static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
     return hipSuccess;
 }
 
-// rows per wave (rw = 1 / 2 / 4) and waves per workgroup (nw = 3 / 4; 3-wave workgroups exist with rw <= 2 only)
-template <typename WT, int KS, int PRO, int EPI>
-static hipError_t gemv_rw(int rw, GemvArgs a, int B, int K, hipStream_t st, int nw = ER_NWAVES) {
-    if constexpr (KS == 1) {
-        if (nw == 3) {
-            if (rw == 1) return gemv_groups<WT, KS, 1, PRO, EPI, 3>(a, B, K, st);
-            return gemv_groups<WT, KS, 2, PRO, EPI, 3>(a, B, K, st);
-        }
-        if (nw == 6) return gemv_groups<WT, KS, 1, PRO, EPI, 6>(a, B, K, st);     // 6 waves x 1 row: 4608 qkv rows = 768 workgroups
-        if (nw == 9) return gemv_groups<WT, KS, 2, PRO, EPI, 9>(a, B, K, st);     // 9 waves x 2 rows: 4608 qkv rows = 256 workgroups, one per CU
-        if (nw == 12) return gemv_groups<WT, KS, 2, PRO, EPI, 12>(a, B, K, st);   // 12 waves x 2 rows: 6144 fc1 rows = 256 workgroups, one per CU
-    }
-    switch (rw) {
-        case 1: return gemv_groups<WT, KS, 1, PRO, EPI>(a, B, K, st);
-        case 4: return gemv_groups<WT, KS, 4, PRO, EPI>(a, B, K, st);
-        default: return gemv_groups<WT, KS, 2, PRO, EPI>(a, B, K, st);
-    }
+// single-row GEMV with a LayerNorm / embedding prologue by waves per workgroup: 4 or 6 waves x 1 row (qkv), 4 waves x 2 rows (fc1),
+// or ONE fat workgroup per CU - 9 waves x 2 rows = 4608 qkv rows / 256, 12 waves x 2 rows = 6144 fc1 rows / 256
+template <typename WT, int PRO, int EPI>
+static hipError_t gemv_nw(int nw, GemvArgs a, int B, int K, hipStream_t st) {
+    if (nw == 6) return gemv_groups<WT, 1, 1, PRO, EPI, 6>(a, B, K, st);
+    if (nw == 9) return gemv_groups<WT, 1, 2, PRO, EPI, 9>(a, B, K, st);
+    if (nw == 12) return gemv_groups<WT, 1, 2, PRO, EPI, 12>(a, B, K, st);
+    if (EPI == EPI_QKV) return gemv_groups<WT, 1, 1, PRO, EPI>(a, B, K, st);
+    return gemv_groups<WT, 1, 2, PRO, EPI>(a, B, K, st);
 }
 
 // B > 4: weights streamed once per pass of up to 16 rows (gemv_batched_kernel)
@@ -748,7 +732,7 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     a.q = c->qbuf;
     a.kcache = (char*)c->kc + (long long)layer * c->kv_lstride * c->kv_esz;
     a.vcache = (char*)c->vc + (long long)layer * c->kv_lstride * c->kv_esz;
-    a.chunk = attn_chunk(c->attn_steps, c->fast);
+    a.chunk = attn_chunk(ATTN_STEPS_DEFAULT, c->fast);
     a.pos = c->st.pos;
     a.fixed_len = c->prof_len;
     a.len_dev = nullptr;
@@ -761,17 +745,15 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     a.hidden = c->cfg.hidden_dim;
     a.kv_bstride = c->kv_bstride;
     a.sqrt_d = sqrtf((float)c->D);
-    a.grid_hs = c->attn_grid_hs;
     return a;
 }
 
 static hipError_t launch_attn_partial(const AttnDecArgs& a, int D, int steps, bool kv_half, int B, hipStream_t st, int ver = 2) {
     return D == 96 ? launch_attn_partial_d<96>(a, steps, kv_half, B, st, ver) : launch_attn_partial_d<64>(a, steps, kv_half, B, st, ver);
 }
-static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int B, hipStream_t st, int ver = 2) {
-    return D == 96 ? launch_attn_combine_d<96>(a, B, st, ver) : launch_attn_combine_d<64>(a, B, st, ver);
+static hipError_t launch_attn_combine(const AttnDecArgs& a, int D, int B, hipStream_t st) {
+    return D == 96 ? launch_attn_combine_d<96>(a, B, st) : launch_attn_combine_d<64>(a, B, st);
 }
-static int env_version(const char* name) { const char* v = getenv(name); return (v && v[0] == '1') ? 1 : 2; }
 
 template <typename WT>
 static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, long long* out_ids, int out_ld) {
@@ -790,7 +772,6 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             a.q = c->qbuf;
             a.kcache = (char*)c->kc + (long long)layer * c->kv_lstride * c->kv_esz;
             a.vcache = (char*)c->vc + (long long)layer * c->kv_lstride * c->kv_esz;
-            if (c->debug_kv_flat) { a.kv_flat = 1; a.kcache = c->fbuf; a.vcache = c->fbuf + H; }
             if (layer == 0) {
                 a.embd = c->embd; a.posemb = c->posemb; a.tok = c->st.tok;
             } else {
@@ -803,19 +784,18 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 if (!c->batched_valu) { a.W = L.wqkv_t; return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, c->skpart, st); }   // 144 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_QKV>(a, B, H, st);   // 4608 rows = 192 workgroups x 24: one round
             }
-            if (layer == 0) return gemv_rw<WT, 1, PRO_EMBED, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
-            return gemv_rw<WT, 1, PRO_LN, EPI_QKV>(c->rw_qkv, a, B, H, st, c->nw_qkv);
+            if (layer == 0) return gemv_nw<WT, PRO_EMBED, EPI_QKV>(c->nw_qkv, a, B, H, st);
+            return gemv_nw<WT, PRO_LN, EPI_QKV>(c->nw_qkv, a, B, H, st);
         }
         // v2 holds a wave's whole K/V slice in flight (latency-bound single rows); with hundreds of workgroups per CU's
         // worth of work (B > 4) the leaner v1 (66-74 VGPRs, 6-7 waves per SIMD) streams faster: 570 vs 636 us at B = 32, L = 18050
         case 1:
             if (c->v3) return launch_attn_partial3_d<96>(attn_args(c, layer), HALF, c->nch3, B, st);
             if (c->stream_attn) return launch_attn_stream_d<96>(attn_args(c, layer), HALF, B, st);
-            return launch_attn_partial(attn_args(c, layer), c->D, c->attn_steps, HALF, B, st,
-                                       (c->batched && c->attn_v_batched != 2) ? 1 : c->attn_v);
+            return launch_attn_partial(attn_args(c, layer), c->D, ATTN_STEPS_DEFAULT, HALF, B, st, c->batched ? 1 : 2);
         case 2:
             if (c->v3 || c->stream_attn) return hipSuccess;      // the merge runs inside the out_proj kernel / there are no partials
-            return launch_attn_combine(attn_args(c, layer), c->D, B, st, c->combine_v);
+            return launch_attn_combine(attn_args(c, layer), c->D, B, st);
         case 3: {   // out_proj + bias + residual(h) -> ypre1
             const LayerW& L = c->layers[layer];
             if (c->v3) {
@@ -826,10 +806,10 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             }
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
             // 48 row tiles of 32: the matrix-core kernel runs on 48 CUs only, but streams the matrix ONCE for 32 rows where the
-            // VALU kernel needs a pass per 16 (ER_OUT_VALU=1 keeps the latter for A/B runs)
-            if (c->batched && !c->batched_valu && !c->out_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, c->skpart, st); }
+            // VALU kernel needs a pass per 16
+            if (c->batched && !c->batched_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, c->skpart, st); }
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
-            return gemv_rw<WT, 1, PRO_NONE, EPI_RESID>(c->rw_out, a, B, H, st, c->nw_out);
+            return gemv_groups<WT, 1, 1, PRO_NONE, EPI_RESID, 3>(a, B, H, st);     // 3 waves x 1 row: 512 workgroups = 2 per CU
         }
         case 4: {   // h1 = LN1(ypre1); f = relu(fc1 h1 + b)
             const LayerW& L = c->layers[layer];
@@ -842,14 +822,14 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 if (!c->batched_valu) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, c->skpart, st); }   // 192 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_RELU>(a, B, H, st);   // 6144 rows = 256 workgroups x 24
             }
-            return gemv_rw<WT, 1, PRO_LN, EPI_RELU>(c->rw_fc1, a, B, H, st, c->nw_fc1);
+            return gemv_nw<WT, PRO_LN, EPI_RELU>(c->nw_fc1, a, B, H, st);
         }
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.w2_h : (const void*)L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
             if (c->batched && !c->batched_valu) { a.W = L.w2_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st); }   // 48 tiles x 4 K-ranges
             if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);
-            return gemv_rw<WT, 4, PRO_NONE, EPI_RESID>(c->rw_fc2, a, B, I, st);
+            return gemv_groups<WT, 4, 2, PRO_NONE, EPI_RESID>(a, B, I, st);
         }
         case 6: {   // logits = lm_head LN2_last(ypre)
             a.W = HALF ? (const void*)c->lm_head_h : (const void*)c->lm_head; a.bias = nullptr; a.N = g.vocab_size; a.xin = c->ypre;
@@ -861,7 +841,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 a.xin = c->hbuf;
                 return gemv_batched_groups<WT, 1, 1, EPI_STORE>(a, B, H, st);
             }
-            return gemv_rw<WT, 1, PRO_LN, EPI_STORE>(1, a, B, H, st);
+            return gemv_groups<WT, 1, 1, PRO_LN, EPI_STORE>(a, B, H, st);
         }
         case 7:
             hipLaunchKernelGGL(sample_head_kernel, dim3(B), dim3(ER_WG), sample_head_lds(g.vocab_size), st, c->logits,
@@ -994,7 +974,7 @@ extern "C" int er_encode_cond(er_ctx* c, const float* conds, int B, int n_points
             HIPRET(linear(c->e_qln.p, PH, c->ca_q_w, c->ca_q_b, c->e_q.p, PH, Lq, PH, PH, false, nullptr, 0, st));
             HIPRET(linear(c->e_x.p, PH, c->ca_k_w, c->ca_k_b, c->e_k.p, PH, (int)R, PH, PH, false, nullptr, 0, st));
             HIPRET(linear(c->e_x.p, PH, c->ca_v_w, c->ca_v_b, c->e_v.p, PH, (int)R, PH, PH, false, nullptr, 0, st));
-            if (c->flash_prefill && (PD == 64 || PD == 96)) {
+            if (PD == 64 || PD == 96) {
                 Flash32Args f{};
                 f.Q = c->e_q.p; f.ldq = PH; f.qs_b = 0; f.qs_h = PD;                      // queries shared by the batch
                 f.K = c->e_k.p; f.ldk = PH; f.ks_b = (long long)N * PH; f.ks_h = PD;
@@ -1077,7 +1057,6 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
     const er_config& g = c->cfg;
     const int H = g.hidden_dim, I = g.intermediate_dim, NH = g.num_heads, D = c->D;
     const int M = B * S;
-    const int ldS = (S + 15) / 16 * 16;
     ERCHK(ensure(c->p_h, (size_t)M * H));
     ERCHK(ensure(c->p_q, (size_t)M * H));
     ERCHK(ensure(c->p_a, (size_t)M * H));
@@ -1100,7 +1079,7 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
             qa.q = q; qa.kcache = (float*)kc; qa.vcache = (float*)vc; qa.S = S; qa.hidden = H; qa.head_dim = D; qa.l_cap = c->Lcap;
             qa.kv_bstride = c->kv_bstride;
             HIPRET(launch_gemm(qa, 1, st));
-            if (c->flash_prefill) {       // causal attention over the prefix, all samples and heads in one launch   modeling_opt.py:229
+            {       // causal attention over the prefix, all samples and heads in one launch   modeling_opt.py:229
                 Flash32Args f{};
                 f.Q = q; f.ldq = H; f.qs_b = (long long)S * H; f.qs_h = D;
                 f.K = (float*)kc; f.ldk = D; f.ks_b = c->kv_bstride; f.ks_h = (long long)c->Lcap * D;
@@ -1108,24 +1087,17 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
                 f.O = a; f.ldo = H; f.os_b = (long long)S * H; f.os_h = D;
                 f.N = S; f.M = S; f.sqrt_d = sqrtf((float)D); f.causal_off = 0;
                 HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
-            } else {
-                ERCHK(ensure(c->p_sc, (size_t)NH * S * ldS));
-                for (int b = 0; b < B; ++b)
-                    ERCHK(attention_full(q + (size_t)b * S * H, H, (float*)kc + b * c->kv_bstride, D, (long long)c->Lcap * D,
-                                         (float*)vc + b * c->kv_bstride, D, (long long)c->Lcap * D, a + (size_t)b * S * H, H,
-                                         c->p_sc.p, NH, D, S, S, true, st));
             }
         } else {
             // fast mode: fused projection into fp32 scratch [M][3H]; K/V rounded to the cache dtype (fp16) both in
             // the cache and in the scratch the prefix attention reads
             ERCHK(ensure(c->p_qkv, (size_t)M * 3 * H));
             float* qkv = c->p_qkv.p;
-            if (c->split_prefill) HIPRET(linear_h(h, H, L.wqkv_h, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
-            else HIPRET(linear(h, H, L.wqkv, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
+            HIPRET(linear_h(h, H, L.wqkv_h, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
             hipLaunchKernelGGL(kv_scatter_half_kernel, dim3(ew_grid((long long)M * 2 * H)), dim3(ER_WG), 0, st, qkv,
                                (_Float16*)kc, (_Float16*)vc, M, S, H, D, c->Lcap, c->kv_bstride);
             HIPRET(hipGetLastError());
-            if (c->flash_prefill) {
+            {
                 Flash32Args f{};
                 f.Q = qkv; f.ldq = 3 * H; f.qs_b = (long long)S * 3 * H; f.qs_h = D;
                 f.K = qkv + H; f.ldk = 3 * H; f.ks_b = f.qs_b; f.ks_h = D;
@@ -1134,17 +1106,10 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
                 f.N = S; f.M = S; f.sqrt_d = sqrtf((float)D); f.causal_off = 0;
                 if (c->prefill_attn_f16s && D == 96) HIPRET(launch_flash_attn_f16s(f, D, true, NH, B, st));   // K / V in the scratch are fp16 values already
                 else HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
-            } else {
-                ERCHK(ensure(c->p_sc, (size_t)NH * S * ldS));
-                for (int b = 0; b < B; ++b) {
-                    float* base = qkv + (size_t)b * S * 3 * H;
-                    ERCHK(attention_full(base, 3 * H, base + H, 3 * H, D, base + 2 * H, 3 * H, D, a + (size_t)b * S * H, H,
-                                         c->p_sc.p, NH, D, S, S, true, st));
-                }
             }
         }
         // y = h + out_proj(a); h1 = LN1(y)                               modeling_opt.py:232, 272-274
-        const bool hs = c->fast && c->split_prefill;
+        const bool hs = c->fast;
         if (hs) HIPRET(linear_h(a, H, L.wo_h, L.bo, y, H, M, H, H, false, h, H, st));
         else HIPRET(linear(a, H, L.wo, L.bo, y, H, M, H, H, false, h, H, st));
         HIPRET(launch_layernorm(y, L.ln1w, L.ln1b, h, M, H, H, H, g.ln_eps, st));
@@ -1377,10 +1342,7 @@ static int profile_impl(er_ctx* c, int repeats, int use_graph, float* avg_us, do
                     HIPCHK(hipGraphLaunch(gexec, st));
                     launches += nl;
                 } else if (per_layer) {
-                    // ER_PROF_LAYERS=n restricts the sweep to the first n layers (cache-residency experiments)
-                    const char* pl = getenv("ER_PROF_LAYERS");
-                    const int span = (pl && atoi(pl) > 0 && atoi(pl) < nl) ? atoi(pl) : nl;
-                    for (int l = 0; l < nl; ++l) { HIPRET(launch_kind(c, kind, l % span, st, dummy_ids, 8)); ++launches; }
+                    for (int l = 0; l < nl; ++l) { HIPRET(launch_kind(c, kind, l, st, dummy_ids, 8)); ++launches; }
                 } else {
                     for (int l = 0; l < nl; ++l) {   // same number of back-to-back launches
                         if (kind == 7) {   // keep the head's step counter in range
@@ -1471,7 +1433,10 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
 }
 
 extern "C" int er_k_attn_decode(const float* q, const void* k, const void* v, const int32_t* len_host, float* out, int B,
-                                int heads, int head_dim, int l_cap, int steps, int kv_half, void* stream) {
+                                int heads, int head_dim, int l_cap, int steps, int kv_half, int variant, void* stream) {
+    if (variant != ER_ATTN_SPLIT1 && variant != ER_ATTN_SPLIT2 && variant != ER_ATTN_STREAM)
+        return fail(ER_ERR_INVALID, "er_k_attn_decode: variant must be ER_ATTN_SPLIT1, ER_ATTN_SPLIT2 or ER_ATTN_STREAM");
+    if (variant == ER_ATTN_STREAM && head_dim != 96) return fail(ER_ERR_UNSUPPORTED, "the streaming kernel is built for head_dim 96");
     if (head_dim != 96 && head_dim != 64) return fail(ER_ERR_UNSUPPORTED, "head_dim %d", head_dim);
     if (steps != 2 && steps != 4 && steps != 8) return fail(ER_ERR_INVALID, "steps must be 2, 4 or 8 (chunk = 32*steps keys)");
     hipStream_t st = (hipStream_t)stream;
@@ -1485,13 +1450,12 @@ extern "C" int er_k_attn_decode(const float* q, const void* k, const void* v, co
     a.q = q; a.kcache = k; a.vcache = v; a.len_dev = len_dev; a.part = part; a.out = out;
     a.H = heads; a.l_cap = l_cap; a.S = S; a.hidden = heads * head_dim; a.chunk = attn_chunk(steps, kv_half != 0);
     a.kv_bstride = (long long)heads * l_cap * head_dim; a.sqrt_d = sqrtf((float)head_dim);
-    const char* sv = getenv("ER_ATTN_V_BATCHED");
     hipError_t e;
-    if (sv && sv[0] == '3' && head_dim == 96) {       // the streaming kernel of the batched decode step (no partials)
+    if (variant == ER_ATTN_STREAM) {       // the streaming kernel of the batched decode step (no partials)
         e = launch_attn_stream_d<96>(a, kv_half != 0, B, st);
     } else {
-        e = launch_attn_partial(a, head_dim, steps, kv_half != 0, B, st, env_version("ER_ATTN_V"));
-        if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st, env_version("ER_COMBINE_V"));
+        e = launch_attn_partial(a, head_dim, steps, kv_half != 0, B, st, variant == ER_ATTN_SPLIT1 ? 1 : 2);
+        if (e == hipSuccess) e = launch_attn_combine(a, head_dim, B, st);
     }
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(len_dev);

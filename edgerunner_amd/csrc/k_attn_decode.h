@@ -39,7 +39,6 @@ struct AttnDecArgs {
     int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS with half the steps)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
-    int grid_hs;           // partial kernels: 1 = grid (H, S, B): heads fastest, so the chunks beyond the current length (which exit at once) are dispatched LAST
 };
 
 __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
@@ -80,10 +79,10 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_kernel(AttnDecArgs a) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & (LPK - 1), g = lane / LPK;
-    // heads fastest (grid_hs): workgroup id = h + H*s lands on XCD h % 8, so every XCD gets the same number of ACTIVE chunks.
+    // heads fastest: workgroup id = h + H*s lands on XCD h % 8, so every XCD gets the same number of ACTIVE chunks.
     // With chunks fastest and S a multiple of 8, chunk s always lands on XCD s % 8: at 33 active chunks XCD 0 works on 5
     // chunks per head while the others hold 4 - the 137 -> 167 us jump of the batch-32 sweep between L = 3926 and 4176.
-    const int s = a.grid_hs ? blockIdx.y : blockIdx.x, h = a.grid_hs ? blockIdx.x : blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
     const int len = attn_len(a, b);
     const int k0 = s * CHUNK;
     if (k0 >= len) return;                    // inactive chunk: the merge only visits ceil(len/CHUNK) partials
@@ -186,55 +185,7 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_kernel(AttnDecArgs a) {
     if (tid == 0) { pout[0] = m; pout[1] = l; }
 }
 
-// grid (H, B), 256 threads: merge the active partial softmaxes of one (b, h).  Latency-bound (a few KB
-// from L2), so it is organised as two rounds of independent loads instead of a serial walk over the
-// partials: round 1 fetches every {m_s, l_s} at once (one per thread) and turns them into the merge
-// weights w_s = exp(m_s - M) in LDS; round 2 has thread (c, half) accumulate column c over the
-// partials of its half with unrolled, independent loads.
-template <int D>
-__global__ __launch_bounds__(ER_WG) void attn_combine_kernel(AttnDecArgs a) {
-    const int CHUNK = a.chunk;
-    constexpr int W = D + 2;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [S] merge weights + [128] half sums + [8]
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int n_act = (attn_len(a, b) + CHUNK - 1) / CHUNK;
-    float* wts = smem;
-    float* half1 = smem + a.S;
-    float* red = half1 + 128;
-    const float* pb = a.part + ((long long)b * a.H + h) * a.S * W;
-    // round 1
-    float mloc = -INFINITY;
-    for (int s = tid; s < n_act; s += ER_WG) mloc = fmaxf(mloc, pb[s * W]);
-    const float M = block_max(mloc, red);
-    float lloc = 0.f;
-    for (int s = tid; s < n_act; s += ER_WG) {
-        const float w = expf(pb[s * W] - M);
-        wts[s] = w;
-        lloc = fmaf(pb[s * W + 1], w, lloc);
-    }
-    const float l = block_sum(lloc, red);            // barriers inside publish wts[]
-    // round 2
-    const int c = tid & 127, half = tid >> 7;
-    float o = 0.f;
-    if (c < D) {
-        const float* col = pb + 2 + c;
-        int s = half;
-        for (; s + 14 < n_act; s += 16) {            // 8 independent loads in flight
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(s + 2 * u) * W];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o = fmaf(v[u], wts[s + 2 * u], o);
-        }
-        for (; s < n_act; s += 2) o = fmaf(col[s * W], wts[s], o);
-    }
-    if (half == 1) half1[c] = o;
-    __syncthreads();
-    if (half == 0 && c < D) a.out[(long long)b * a.hidden + h * D + c] = (o + half1[c]) / l;
-}
-
-
-// ---- version 2 of both kernels (default; ER_ATTN_V=1 / ER_COMBINE_V=1 select the originals above for A/B runs).
+// ---- version 2 of the partial kernel and the merge kernel (the round-1 merge, a serial walk over the partials, is gone).
 //
 // attn_decode2_kernel: same work decomposition and loads as attn_decode_kernel, but every WAVE runs its own softmax
 // (max / sum through shuffles only) and the four waves are merged once through LDS - one workgroup barrier on the
@@ -251,7 +202,7 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
     __shared__ float wm[ER_NWAVES], wl[ER_NWAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & (LPK - 1), g = lane / LPK;
-    const int s = a.grid_hs ? blockIdx.y : blockIdx.x, h = a.grid_hs ? blockIdx.x : blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
     const int len = attn_len(a, b);
     const int k0 = s * CHUNK;
     if (k0 >= len) return;
@@ -794,9 +745,8 @@ inline int attn_num_chunks(int l_cap, int chunk) { return (l_cap + chunk - 1) / 
 // `steps` is the fp32 step count (chunk = 32*steps keys); fp16 KV uses half as many steps for the same chunk.
 template <int D>
 inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv_half, int B, hipStream_t st, int version = 2) {
-    const dim3 grid = a.grid_hs ? dim3(a.H, a.S, B) : dim3(a.S, a.H, B), blk(ER_WG);
+    const dim3 grid(a.H, a.S, B), blk(ER_WG);      // heads fastest: XCD = head mod 8 (see attn_decode_kernel)
     if (version == 2) {
-        const dim3 grid = a.grid_hs ? dim3(a.H, a.S, B) : dim3(a.S, a.H, B);
         if (!kv_half) {
             if (steps == 2) hipLaunchKernelGGL((attn_decode2_kernel<float, D, 2>), grid, blk, 0, st, a);
             else if (steps == 8) hipLaunchKernelGGL((attn_decode2_kernel<float, D, 8>), grid, blk, 0, st, a);
@@ -820,14 +770,8 @@ inline hipError_t launch_attn_partial_d(const AttnDecArgs& a, int steps, bool kv
     return hipGetLastError();
 }
 template <int D>
-inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int B, hipStream_t st, int version = 2) {
-    const dim3 grid(a.H, B), blk(ER_WG);
-    if (version == 2) {
-        hipLaunchKernelGGL((attn_combine2_kernel<D>), grid, blk, 0, st, a);
-        return hipGetLastError();
-    }
-    const size_t lds = (size_t)(a.S + 128 + 8) * sizeof(float);
-    hipLaunchKernelGGL((attn_combine_kernel<D>), grid, blk, lds, st, a);
+inline hipError_t launch_attn_combine_d(const AttnDecArgs& a, int B, hipStream_t st) {
+    hipLaunchKernelGGL((attn_combine2_kernel<D>), dim3(a.H, B), dim3(ER_WG), 0, st, a);
     return hipGetLastError();
 }
 

@@ -46,7 +46,6 @@ struct GemvArgs {
     void* kcache;          //          [B][H][Lcap][D] (this layer), fp32 or fp16
     void* vcache;
     int kv_half;           //          1: the cache holds _Float16
-    int kv_flat;           //          timing probe only (ER_DEBUG_KV_FLAT=1): k/v go to one contiguous row instead of cache row `pos`
     int hidden, head_dim, l_cap;
     long long kv_bstride;  // H*Lcap*D
 };
@@ -103,7 +102,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, f
         } else {
             const int h = c / a.head_dim, d = c - h * a.head_dim;
             void* cache = (which == 1) ? a.kcache : a.vcache;
-            const long long idx = a.kv_flat ? (long long)c : (long long)b * a.kv_bstride + ((long long)h * a.l_cap + e.pos) * a.head_dim + d;
+            const long long idx = (long long)b * a.kv_bstride + ((long long)h * a.l_cap + e.pos) * a.head_dim + d;
             if (a.kv_half) reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)v;     // round-to-nearest-even
             else reinterpret_cast<float*>(cache)[idx] = v;
         }

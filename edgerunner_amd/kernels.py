@@ -27,13 +27,14 @@ def gemv(w, x, bias=None, ln_w=None, ln_b=None, resid=None, relu=False, eps=1e-5
     return (y, xn) if return_xnorm else y
 
 
-def attn_decode(q, k_cache, v_cache, lens, steps=4):
-    """q [B,H*D] fp32; caches [B,H,Lcap,D] fp32 or fp16; lens: list[int] -> out [B,H*D]."""
+def attn_decode(q, k_cache, v_cache, lens, steps=4, variant=native.ER_ATTN_SPLIT2):
+    """q [B,H*D] fp32; caches [B,H,Lcap,D] fp32 or fp16; lens: list[int] -> out [B,H*D].
+    variant: native.ER_ATTN_SPLIT2 (single-row fallback), ER_ATTN_SPLIT1 (mid-size batches) or ER_ATTN_STREAM (B * heads >= 256)."""
     lib = native.load_library()
     B, H, Lcap, D = k_cache.shape
     out = torch.empty((B, H * D), dtype=torch.float32, device=q.device)
     native.check(lib.er_k_attn_decode(native.ptr(q), native.ptr(k_cache), native.ptr(v_cache), native.i32_array(lens),
-                                      native.ptr(out), B, H, D, Lcap, steps, int(k_cache.dtype == torch.float16), _st()),
+                                      native.ptr(out), B, H, D, Lcap, steps, int(k_cache.dtype == torch.float16), int(variant), _st()),
                  "er_k_attn_decode")
     return out
 

@@ -261,6 +261,12 @@ class NativeShapeOPT:
             self.feed(nxt)
         return ids.to(self.device)
 
+    def plan(self):
+        """Kernel selection of THIS context for its reserved cache (``er_ctx_plan``): dict of the ``er_decode_plan`` fields."""
+        p = native.ErDecodePlan()
+        native.check(self.lib.er_ctx_plan(self._ctx, C.byref(p)), "er_ctx_plan")
+        return {n: int(getattr(p, n)) for n, _ in native.ErDecodePlan._fields_}
+
     # -- measurement -------------------------------------------------------------------------
     def profile_decode_kernels(self, repeats: int = 5, context_len: int = 0, use_graph: bool = False):
         """Per-kind average launch duration (HIP events on the launch stream) and algorithmic bytes per launch.

@@ -208,6 +208,17 @@ def synthetic_point_cloud(index: int, num_points: int = 4096) -> torch.Tensor:
     return (torch.rand(num_points, 3, generator=g, dtype=torch.float32) * 1.9 - 0.95).unsqueeze(0)
 
 
+def synthetic_resume_ids(seed: int, n: int):
+    """n token ids that obey the LR_ABSCO layout (core/models.py:246-268: BOM + 9 coordinates, then (L | R) + 3 coordinates ...),
+    as int64 numpy: the resumed prefix of the long-context parity cases (``resume_ids``, core/models.py:225-226)."""
+    import numpy as np
+    g = np.random.default_rng(seed)
+    out = [5] + [int(v) for v in g.integers(6, 518, 9)]
+    while len(out) < n:
+        out += [int(g.integers(3, 5))] + [int(v) for v in g.integers(6, 518, 3)]
+    return np.asarray(out[:n], dtype=np.int64)
+
+
 # ------------------------------------------------------------------------------------ DiT front-end (f3)
 def dit_tensor_specs(opt, clip_dim: int = 1280) -> List[Tuple[str, Tuple[int, ...], str]]:
     """(key, shape, kind) of the MDiT checkpoint entries the denoiser reads (core/models_dit.py:43-63 /

@@ -215,6 +215,8 @@ typedef struct {
                                    layers x this + lm_head + sample_head launches */
 } er_decode_plan;
 int er_plan_decode(int batch, int heads, int head_dim, int hidden, int l_cap, er_decode_plan* out);
+/* the plan of a live context (knobs as read by er_create, cache as reserved by the last er_kv_reserve) */
+int er_ctx_plan(er_ctx* ctx, er_decode_plan* out);
 /* tile shape launch_gemm* picks for an [m, n] output in `batch` slices: 1 = 128x128, 2 = 64x128, 3 = 64x64 (ER_GEMM_TILE forces) */
 int er_plan_gemm_tile(int m, int n, int batch);
 
@@ -245,10 +247,12 @@ int er_k_gemv(const float* w_dev, const float* bias_dev, const float* x_dev, con
               const float* ln_b_dev, const float* resid_dev, float* y_dev, float* xnorm_out_dev,
               int batch, int n, int k, int relu, float eps, void* stream);
 /* softmax(q K^T / sqrt(D)) V for one new token over a [B,H,Lcap,D] cache holding len[b] keys;
- * steps in {2,4,8}: one workgroup per chunk of 32*steps keys */
+ * steps in {2,4,8}: one workgroup per chunk of 32*steps keys (split kernels); variant = ER_ATTN_SPLIT2 (the single-row fallback:
+ * per-wave softmax + one-round-trip merge kernel), ER_ATTN_SPLIT1 (the leaner split kernel of mid-size batches + the same merge)
+ * or ER_ATTN_STREAM (one workgroup per (row, head) walks the whole key range, head_dim 96 only) */
 int er_k_attn_decode(const float* q_dev, const void* k_dev, const void* v_dev, const int32_t* len_host,
                      float* out_dev, int batch, int heads, int head_dim, int l_cap, int steps, int kv_half,
-                     void* stream);
+                     int variant, void* stream);
 /* Version 3 of the single-row decode attention (env ER_DECODE_V=3), one row, 16 heads of 96:
  * y[1536] = Wo . softmax(q K^T / sqrt(D)) V + bo + resid over a [16,Lcap,96] cache holding len keys (Lcap <= 8192):
  * balanced chunks (16 per head) + the partial merge fused into the out_proj GEMV; w_half: Wo is fp16 */

@@ -11,6 +11,7 @@ Usage:  python oracle/make_golden.py small|eos  # ~1 min each
         python oracle/make_golden.py full       # ~10 min (24 layers, T=4000)
         python oracle/make_golden.py dit_full   # ~5 min (24 DiT + 32 CLIP layers, 3 DDIM steps)
         python oracle/make_golden.py batch      # ~6 min (24 layers, 3 rows x 3 modes x 48 steps)
+        python oracle/make_golden.py long       # ~10 min, ~40 GB RAM (2 layers, 12000 resumed tokens: decode from context 14050)
 Fixtures are small .npz files; the weights are regenerated from the seed by
 ``edgerunner_amd.weights`` (never committed).
 """
@@ -372,6 +373,37 @@ def make_batch(T=48):
     print({k: v.shape for k, v in out.items()})
 
 
+@torch.no_grad()
+def make_long(R=12000, T=40):
+    """Long-context decode (VERDICT r2 'parity beyond ~8 k keys'): 2 layers, clouds 0 / 7 / 17 of an 18-row batch, each with
+    R = 12000 resumed tokens (core/models.py:225-226), so the prefix is 2049 + 1 + R = 14050 positions and the T greedy steps run
+    at contexts 14050 .. 14050 + T - where the single-row path uses its fixed-chunk fallback (reserved cache > 8192 keys) and
+    the batch path the streaming attention kernel.  Reference modules unmodified (the naive attention materialises
+    16 x 14050^2 scores: ~38 GB peak), per-step logits kept for the teacher-forced comparison."""
+    opt, ref_opt = opts(2, generate_mode="greedy")
+    sd = W.make_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE)
+    model = build_reference(ref_opt, sd)
+    rows = [0, 7, 17]
+    out = {"rows": np.array(rows), "T": np.array([T]), "R": np.array([R])}
+    ids, lg, res = [], [], []
+    t0 = time.time()
+    for r in rows:
+        pc = W.synthetic_point_cloud(r, 4096)
+        resume = W.synthetic_resume_ids(500 + r, R)
+        i, l = run_case(model, sd, opt, pc, 4000, T, T, resume_ids=torch.from_numpy(resume)[None], n_logits=T,
+                        check_restatement=(r == 0))
+        ids.append(i[0]); lg.append(l[:, 0]); res.append(resume.astype(np.int16))
+        print(f"row {r}: {time.time() - t0:.0f}s  ids {i[0][:12]}", flush=True)
+    import zlib
+    out.update(ids=np.stack(ids), logits=np.stack(lg), resume_seed_base=np.array([500]),
+               resume_crc32=np.array([zlib.crc32(r_.astype(np.int64).tobytes()) for r_ in res], dtype=np.int64))
+    np.savez_compressed(os.path.join(GOLD, "arae_long.npz"), **out)
+    manifest_update("arae_long", {"num_layers": 2, "rows": rows, "T": T, "resume_tokens": R, "num_faces": 4000,
+                                  "resume": "edgerunner_amd.weights.synthetic_resume_ids(500 + row, R)",
+                                  "context": [2050 + R, 2050 + R + T],
+                                  "cases": {k: list(v.shape) for k, v in out.items()}})
+    print({k: v.shape for k, v in out.items()})
+
 
 @torch.no_grad()
 def make_dit_full(steps=3):
@@ -422,5 +454,7 @@ if __name__ == "__main__":
         make_batch()
     elif what == "dit_full":
         make_dit_full()
+    elif what == "long":
+        make_long()
     else:
         raise SystemExit(__doc__)

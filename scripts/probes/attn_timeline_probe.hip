@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
         AttnDecArgs a{};
         a.q = q; a.kcache = (char*)kc + l * layer_elems * esz; a.vcache = (char*)vc + l * layer_elems * esz;
         a.pos = pos; a.fixed_len = use_fixed ? len : 0; a.len_dev = nullptr; a.part = part; a.part_ml = part_ml; a.out = nullptr;
-        a.H = H; a.l_cap = Lcap; a.S = l; a.hidden = 1536; a.chunk = 0; a.kv_bstride = (long long)layer_elems; a.sqrt_d = sqrtf(96.f); a.grid_hs = 1;
+        a.H = H; a.l_cap = Lcap; a.S = l; a.hidden = 1536; a.chunk = 0; a.kv_bstride = (long long)layer_elems; a.sqrt_d = sqrtf(96.f);
         if (!half) hipLaunchKernelGGL((attn3_timed<float, 4>), dim3(16, 16, 1), dim3(1024), 128, st, a);
         else hipLaunchKernelGGL((attn3_timed<_Float16, 2>), dim3(16, 16, 1), dim3(1024), 128, st, a);
     }

@@ -64,3 +64,11 @@ def gold_batch():
     if not os.path.exists(p):
         pytest.skip("batched-path golden not generated")
     return dict(np.load(p))
+
+
+@pytest.fixture(scope="session")
+def gold_long():
+    p = os.path.join(GOLDEN, "arae_long.npz")
+    if not os.path.exists(p):
+        pytest.skip("long-context golden not generated")
+    return dict(np.load(p))

@@ -134,10 +134,18 @@ def test_gemv_batched_valu_rows_bit_identical_to_single(B, monkeypatch):
 
 
 # ------------------------------------------------------------------ decode attention
+# contexts beyond 8192 keys: configs[2] runs the decode attention to 18050 keys, the position table allows 43008
+LONG_LENS = [(96, [8193, 12000], 4), (96, [18050, 8192], 4), (96, [43008], 4)]
+
+
+@pytest.mark.parametrize("variant", ["split2", "split1"])
 @pytest.mark.parametrize("D,lens,steps", [(96, [2051], 4), (96, [1, 33], 4), (96, [6049, 4000, 17], 4),
-                                          (64, [300], 4), (96, [2050, 129], 2), (96, [2050, 255, 256, 257], 8)])
-def test_attn_decode(D, lens, steps):
-    from edgerunner_amd import kernels as K
+                                          (64, [300], 4), (96, [2050, 129], 2), (96, [2050, 255, 256, 257], 8)] + LONG_LENS)
+def test_attn_decode(D, lens, steps, variant):
+    """split2 = the single-row fallback (reserved caches > 8192 keys, B = 2..4), split1 = the leaner split kernel of the
+    4 < B < 16 batches; both feed the same merge kernel (64 partials per pass: > 8192 keys take several passes)."""
+    from edgerunner_amd import kernels as K, native
+    variant = native.ER_ATTN_SPLIT2 if variant == "split2" else native.ER_ATTN_SPLIT1
     B, H = len(lens), 16
     Lcap = (max(lens) + 31) // 32 * 32
     q = rnd(B, H * D, seed=20)
@@ -146,7 +154,7 @@ def test_attn_decode(D, lens, steps):
     for b, n in enumerate(lens):
         kc[b, :, n:] = float("nan")
         vc[b, :, n:] = float("nan")
-    out = K.attn_decode(q, kc, vc, lens, steps)
+    out = K.attn_decode(q, kc, vc, lens, steps, variant)
     for b, n in enumerate(lens):
         qq = q[b].view(H, 1, D).double()
         w = torch.softmax(qq @ kc[b, :, :n].double().transpose(1, 2) / math.sqrt(D), dim=-1)
@@ -154,9 +162,11 @@ def test_attn_decode(D, lens, steps):
         close(out[b], ref, 2e-6, 1e-5, f"attn row {b} len {n}")
 
 
-@pytest.mark.parametrize("D,lens,steps", [(96, [2051, 700], 4), (96, [1, 65, 6049], 4), (64, [300], 2), (96, [129], 8)])
-def test_attn_decode_fp16_cache(D, lens, steps):
-    from edgerunner_amd import kernels as K
+@pytest.mark.parametrize("variant", ["split2", "split1"])
+@pytest.mark.parametrize("D,lens,steps", [(96, [2051, 700], 4), (96, [1, 65, 6049], 4), (64, [300], 2), (96, [129], 8)] + LONG_LENS)
+def test_attn_decode_fp16_cache(D, lens, steps, variant):
+    from edgerunner_amd import kernels as K, native
+    variant = native.ER_ATTN_SPLIT2 if variant == "split2" else native.ER_ATTN_SPLIT1
     B, H = len(lens), 16
     Lcap = (max(lens) + 63) // 64 * 64
     q = rnd(B, H * D, seed=23)
@@ -164,7 +174,7 @@ def test_attn_decode_fp16_cache(D, lens, steps):
     for b, n in enumerate(lens):
         kc[b, :, n:] = float("nan")
         vc[b, :, n:] = float("nan")
-    out = K.attn_decode(q, kc, vc, lens, steps)
+    out = K.attn_decode(q, kc, vc, lens, steps, variant)
     for b, n in enumerate(lens):
         w = torch.softmax(q[b].view(H, 1, D).double() @ kc[b, :, :n].double().transpose(1, 2) / math.sqrt(D), dim=-1)
         close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"fp16-KV attn row {b} len {n}")
@@ -190,15 +200,15 @@ def test_flash_attn_f16s_staged(B, H, N, M, causal):
     close(o, ref, 3e-6, 1e-5, "split-fp16 flash attention")
 
 
+@pytest.mark.parametrize("lens", [[2051, 700, 1, 65, 6049, 128, 129, 63], [18050, 8193, 12000, 43008, 16383]])
 @pytest.mark.parametrize("half", [False, True])
-def test_attn_decode_streaming_kernel(monkeypatch, half):
-    """ER_ATTN_V_BATCHED=3: one workgroup per (row, head) walks the whole key range with a running softmax per wave
-    (double-buffered register tiles, no partials, no merge kernel).  Ragged lengths incl. 1 key and a non-multiple of the tile."""
-    from edgerunner_amd import kernels as K
-    monkeypatch.setenv("ER_ATTN_V_BATCHED", "3")
-    lens = [2051, 700, 1, 65, 6049, 128, 129, 63]
+def test_attn_decode_streaming_kernel(half, lens):
+    """The batch attention of B * heads >= 256: one workgroup per (row, head) walks the whole key range with a running softmax per
+    wave (double-buffered register tiles, no partials, no merge kernel).  Ragged lengths incl. 1 key, a non-multiple of the tile,
+    and the long contexts of configs[2] (18050) up to the position table's 43008."""
+    from edgerunner_amd import kernels as K, native
     B, H, D = len(lens), 16, 96
-    Lcap = 6080
+    Lcap = (max(lens) + 31) // 32 * 32
     q = rnd(B, H * D, seed=70)
     kc, vc = rnd(B, H, Lcap, D, seed=71), rnd(B, H, Lcap, D, seed=72)
     if half:
@@ -206,7 +216,7 @@ def test_attn_decode_streaming_kernel(monkeypatch, half):
     for b, n in enumerate(lens):
         kc[b, :, n:] = float("nan")
         vc[b, :, n:] = float("nan")
-    out = K.attn_decode(q, kc, vc, lens, 4)
+    out = K.attn_decode(q, kc, vc, lens, 4, native.ER_ATTN_STREAM)
     for b, n in enumerate(lens):
         w = torch.softmax(q[b].view(H, 1, D).double() @ kc[b, :, :n].double().transpose(1, 2) / math.sqrt(D), dim=-1)
         close(out[b], (w @ vc[b, :, :n].double()).reshape(H * D), 2e-6, 1e-5, f"streaming attn row {b} len {n}")

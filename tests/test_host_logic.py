@@ -271,8 +271,8 @@ def test_decode_plan_batched_attention(monkeypatch):
     assert _plan(8, 6051).attn_kernel == native.ER_ATTN_STREAM
     monkeypatch.setenv("ER_ATTN_V_BATCHED", "1")
     assert _plan(32, 6051).attn_kernel == native.ER_ATTN_SPLIT1
-    monkeypatch.setenv("ER_ATTN_V_BATCHED", "2")
-    assert _plan(32, 6051).attn_kernel == native.ER_ATTN_SPLIT2
+    monkeypatch.setenv("ER_ATTN_V_BATCHED", "2")                         # not a value any more: auto
+    assert _plan(32, 6051).attn_kernel == native.ER_ATTN_STREAM
 
 
 def test_gemm_tile_choice_follows_workgroups_per_cu():

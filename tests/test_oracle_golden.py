@@ -105,6 +105,34 @@ def test_full_golden_is_well_formed(gold_full, manifest):
         hist = torch.cat([hist, torch.tensor([ids[t]])])
 
 
+def test_long_context_golden_is_well_formed(gold_long, manifest):
+    """The long-context fixture (reference modules, 12000 resumed tokens, contexts 14050..14090): the resumed prefixes the GPU tests
+    rebuild from the seed are the ones the reference saw (CRC), they obey the LR_ABSCO layout, and every golden id is the
+    grammar-masked arg max of its recorded logits.  (Re-running the reference prefill needs ~38 GB and minutes: make_golden.py long.)"""
+    import zlib
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.grammar import GrammarState
+    from edgerunner_amd import native
+    rows, R, T = [int(r) for r in gold_long["rows"]], int(gold_long["R"][0]), int(gold_long["T"][0])
+    assert manifest["arae_long"]["context"] == [2050 + R, 2050 + R + T] and 2050 + R > 8192
+    fn = O.make_allowed_fn(config_defaults["ArAE"], 518)
+    for i, r in enumerate(rows):
+        res = W.synthetic_resume_ids(int(gold_long["resume_seed_base"][0]) + r, R)
+        assert zlib.crc32(res.astype(np.int64).tobytes()) == int(gold_long["resume_crc32"][i])
+        st, last = GrammarState(native.ER_GRAMMAR_LR_ABSCO, 518), None
+        for t in res[:2000].tolist():
+            assert t in st.allowed(last) and t != 2
+            last = t
+        hist = torch.empty(0, dtype=torch.long)
+        for t in range(T):
+            s = torch.from_numpy(gold_long["logits"][i, t]).clone()
+            s[2] = -float("inf")
+            mask = torch.full_like(s, -float("inf"))
+            mask[fn(0, hist)] = 0
+            assert int(torch.argmax(s + mask)) == int(gold_long["ids"][i, t]), (r, t)
+            hist = torch.cat([hist, torch.tensor([int(gold_long["ids"][i, t])])])
+
+
 # ------------------------------------------------------------------ DiT / CLIP front-end (scope row f3)
 @pytest.fixture(scope="module")
 def gold_dit():
