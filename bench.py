@@ -7,7 +7,11 @@ grammar head (LMM.generate; reference core/models.py:204-303).  Default workload
 configs[1]: ArAE (24 layers, 1536 wide) random-init, batch 1, greedy, test_num_face=1000,
 T = 4*num_faces = 4000 new tokens with EOS suppressed until T, 4096-point cloud, exact fp32
 mode (the mode whose greedy ids are bit-exact vs the reference CPU path).
-``--batch-per-gpu 32`` is BASELINE configs[3]'s shard (256 clouds over 8 GPUs = 32 per GPU).
+``--config 2`` / ``--config 3`` run the other single-GPU configurations of BASELINE.json at FULL size, each with its own
+roofline block: 2 = configs[2] (batch 32, SAMPLE mode top-k 10, test_num_face=4000 -> T = 16000 tokens, context 2050 -> 18050, fp16
+storage: the long-sequence KV-cache case, ~2.5 min per step), 3 = configs[3]'s per-GPU shard (32 clouds per GPU, greedy,
+test_num_face=1000, T = 4000, fp16 storage).  Explicit flags (--batch-per-gpu, --num-face, --precision, --mode, --tokens) override
+the configuration's values.
 
 N > 1: one process per GPU.  ``python bench.py --gpus N`` launches the N ranks itself (re-executes under
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``) unless it already runs
@@ -41,6 +45,13 @@ PREFIX = 2050                  # 2049 condition tokens + BOS
 LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "out_proj_gemv": 24, "fc1_gemv": 24,
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_hbm_summary.json")
+# the single-GPU configurations of BASELINE.json (configs[0] is the CPU path = cpu_baseline; configs[4] = dit_front_end_fp16)
+CONFIGS = {
+    1: {"name": "BASELINE configs[1]", "batch": 1, "num_face": 1000, "mode": "greedy", "precision": "fp32"},
+    2: {"name": "BASELINE configs[2]", "batch": 32, "num_face": 4000, "mode": "sample", "precision": "fp16"},
+    3: {"name": "BASELINE configs[3] shard (32 of the 256 clouds per GPU)", "batch": 32, "num_face": 1000, "mode": "greedy",
+        "precision": "fp16"},
+}
 
 
 def parse_args(argv=None):
@@ -48,8 +59,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-per-gpu", type=int, default=1, help="clouds per generate() call per GPU (32 = configs[3] shard)")
-    ap.add_argument("--num-face", type=int, default=1000)
+    ap.add_argument("--config", type=int, choices=(1, 2, 3), default=1,
+                    help="BASELINE.json configuration: 1 = configs[1] (default: B = 1 greedy, exact fp32), 2 = configs[2] (B = 32 sample "
+                         "mode, test_num_face 4000, fp16), 3 = configs[3] shard (B = 32 greedy, fp16)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="clouds per generate() call per GPU (default: the configuration's)")
+    ap.add_argument("--num-face", type=int, default=None)
+    ap.add_argument("--mode", choices=("greedy", "sample"), default=None)
     ap.add_argument("--tokens", type=int, default=None, help="new tokens per sample (default 4*num_face)")
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--points", type=int, default=4096)
@@ -57,12 +72,20 @@ def parse_args(argv=None):
                     help="extra teacher-given tokens appended to the prefix (resume_ids): starts the decode at a longer "
                          "context; used by the PMC passes to measure attention traffic at the run's mean context length")
     ap.add_argument("--cpu-steps", type=int, default=120, help="decode steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=("fp32", "fp16"), default="fp32",
-                    help="fp32 = exact mode (the mode whose ids are bit-exact vs the CPU path; default); fp16 = fast mode")
+    ap.add_argument("--precision", choices=("fp32", "fp16"), default=None,
+                    help="fp32 = exact mode (the mode whose ids are bit-exact vs the CPU path; configs[1]); fp16 = fast mode")
     ap.add_argument("--no-fast-extra", action="store_true", help="skip the additional fp16 fast-mode / batch-32 measurements")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: fabricated streams through the same multi-rank plumbing")
     ap.add_argument("--master-port", type=int, default=0)
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    cfg = CONFIGS[a.config]
+    a.overridden = [k for k, v in (("batch_per_gpu", a.batch_per_gpu), ("num_face", a.num_face), ("mode", a.mode),
+                                   ("precision", a.precision), ("tokens", a.tokens)) if v is not None]
+    a.batch_per_gpu = cfg["batch"] if a.batch_per_gpu is None else a.batch_per_gpu
+    a.num_face = cfg["num_face"] if a.num_face is None else a.num_face
+    a.mode = cfg["mode"] if a.mode is None else a.mode
+    a.precision = cfg["precision"] if a.precision is None else a.precision
+    return a
 
 
 def free_port() -> int:
@@ -153,7 +176,21 @@ def cpu_baseline(opt, sd, T_sample, num_points, budget_s=45.0):
         pass
     dec = np.diff(np.array(marks))
     n = len(dec)
+    full = {}
+    try:     # BASELINE.md section 2 protocol (full T, three phases): the committed run of the build container (make_golden.py full)
+        m = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST.json")))["arae_full_T4000"]
+        full = {"T": m["T"], "threads": m["cpu_threads"], "host": m.get("cpu_host", "build container"),
+                "phase_i_encode_s": m.get("cpu_encode_s"), "phase_ii_prefill_s": m.get("cpu_prefill_s"),
+                "phase_iii_decode_s": round(m["T"] / m["cpu_decode_tok_per_s"], 1),
+                "decode_tokens_per_s": round(m["cpu_decode_tok_per_s"], 3),
+                "end_to_end_tokens_per_s": round(m["T"] / m["cpu_seconds_total"], 3),
+                "ms_per_token_first100": round(m["cpu_ms_per_token_first100"], 1),
+                "ms_per_token_last100": round(m["cpu_ms_per_token_last100"], 1),
+                "source": "tests/golden/MANIFEST.json (the 4000-token reference-module run that produced the golden ids; NOT this box)"}
+    except Exception:  # noqa: BLE001
+        pass
     return {
+        "full_run": full,
         "value": round(float(n / dec.sum()), 3), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(),
         "thread_probe_s_per_step_2layers": {str(k): round(v, 5) for k, v in timings.items()},
         "kind": "port",
@@ -205,21 +242,25 @@ def kernel_names(precision, batched):
     """rocprofv3 names of the decode kernels per kind for this build's default knobs (scripts/roofline_from_rocprof.py and
     the PMC summary are matched on them); gemv_kernel<WT, KS, NB, RW, PRO, EPI, NW>."""
     wt = "float" if precision == "fp32" else "_Float16"
-    nwq = os.environ.get("ER_NW_QKV", "6")
-    nwq = nwq if nwq in ("3", "4") else "6"      # er_create's rule
+    fast = precision != "fp32"
+    nwq = os.environ.get("ER_NW_QKV", "9" if fast else "6")     # er_create's rule: 4 / 6 / 9 waves (9 = one fat workgroup per CU)
+    nwq = nwq if nwq in ("4", "9") else "6"
+    nwf = "12" if os.environ.get("ER_NW_FC1", "12" if fast else "4") == "12" else "4"
+    qkv = f"gemv_kernel<{wt}, 1, 1, {2 if nwq == '9' else 1}, 1, 3, {nwq}>"
+    fc1 = f"gemv_kernel<{wt}, 1, 1, 2, 1, 1, {nwf}>"
     if batched:     # B*16 >= 256: one streaming workgroup per (row, head); smaller batches keep the split round-1 kernel (er_api.hip, kind 1)
         return {"attn_decode": [f"attn_stream_kernel<{wt}, 96, 2>", f"attn_decode_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
     if os.environ.get("ER_DECODE_V", "3") != "2":     # default: balanced chunks, merge fused into out_proj (no merge kernel)
-        return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, {nwq}>"],
+        return {"qkv_gemv": [qkv],
                 "attn_decode": [f"attn_decode3_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}, 16>"],
                 "out_proj_gemv": [f"outproj_merge_kernel<{wt}, 96, 16>"],
-                "fc1_gemv": [f"gemv_kernel<{wt}, 1, 1, 2, 1, 1, 4>"], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
+                "fc1_gemv": [fc1], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
                 "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 0, 4>"], "sample_head": ["sample_head_kernel"]}
-    return {"qkv_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 3, {nwq}>"],
+    return {"qkv_gemv": [qkv],
             "attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"],
             "attn_combine": ["attn_combine2_kernel<96>"],
             "out_proj_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 0, 2, 3>"],
-            "fc1_gemv": [f"gemv_kernel<{wt}, 1, 1, 2, 1, 1, 4>"], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
+            "fc1_gemv": [fc1], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
             "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 0, 4>"], "sample_head": ["sample_head_kernel"]}
 
 
@@ -278,12 +319,12 @@ def main(argv=None):
     dev = torch.device("cuda", local)
     T = args.tokens or 4 * args.num_face
     B = args.batch_per_gpu
-    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=args.layers, generate_mode="greedy")
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=args.layers, generate_mode=args.mode)
 
     t0 = time.time()
     lmm = LMM(opt, dev, precision=args.precision)
     esz = 4 if args.precision == "fp32" else 2
-    keep_sd = rank == 0 and world == 1 and args.cpu_steps > 0 and B == 1
+    keep_sd = rank == 0 and world == 1 and args.cpu_steps > 0 and args.config == 1 and not args.overridden
     sd = {}
     def items():
         for k, t in W.iter_state_dict(opt, 0, "perturbed"):
@@ -304,7 +345,8 @@ def main(argv=None):
     def one_step(step_idx):
         mine = D.shard_indices(n_items, rank, world)        # cloud index i runs on rank i mod world
         pcs = torch.cat([W.synthetic_point_cloud(step_idx * n_items + i, args.points) for i in mine]).to(dev)   # resident in HBM
-        _, toks = lmm.generate(pcs, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T, resume_ids=resume)
+        _, toks = lmm.generate(pcs, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T, resume_ids=resume,
+                               seed=(1000 + step_idx) if args.mode == "sample" else None)
         streams = D.gather_token_streams([t[args.resume_len:] for t in toks], n_items, device=dev)
         assert len(streams) == n_items and all(len(s) == T for s in streams)
         return lmm.mesh_decoder.last_decode_ms
@@ -381,23 +423,25 @@ def main(argv=None):
                        "frac": round(decode_only / world * bytes_per_token / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
-    cfg_name = "BASELINE configs[1]" if B == 1 else (f"BASELINE configs[3] shard ({B} clouds per GPU)" if B == 32 else f"batch {B} per GPU")
+    cfg_name = CONFIGS[args.config]["name"] + (f" with {', '.join(args.overridden)} overridden" if args.overridden else "")
     out = {
-        "metric": "mesh tokens/sec (whole node), ArAE greedy test_num_face=1000",
+        "metric": f"mesh tokens/sec (whole node), ArAE {args.mode} test_num_face={args.num_face}",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "world_size_seen": world, "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16 storage / f32 accumulate", "data": "synthetic",
-        "config": {"workload": f"{cfg_name}: ArAE random-init (seeded synthetic checkpoint), batch {B} per GPU, greedy, "
+        "config": {"workload": f"{cfg_name}: ArAE random-init (seeded synthetic checkpoint), batch {B} per GPU, "
+                               f"{'greedy' if args.mode == 'greedy' else 'sample mode (top-k 10, Philox inverse-CDF draw on the device)'}, "
                                f"test_num_face={args.num_face}, {T} new tokens (EOS suppressed until T), "
                                f"{args.points}-point synthetic cloud; step = encode_cond + {L0}-token prefill + {T}-token decode"
                                f"{' + RCCL all-gather of token streams' if world > 1 else ''}",
-                   "layers": args.layers, "hidden": 1536, "heads": 16, "tokens_per_sample": T, "batch_per_gpu": B,
+                   "baseline_config": args.config, "layers": args.layers, "hidden": 1536, "heads": 16, "tokens_per_sample": T,
+                   "batch_per_gpu": B, "generate_mode": args.mode, "precision": args.precision,
                    "parallelism": f"dp{world} (independent samples, full replica per GPU)"},
         "decode_only_tokens_per_s": round(decode_only, 2),
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and B == 1 and args.precision == "fp32" and not args.no_fast_extra:
+    if rank == 0 and world == 1 and args.config == 1 and not args.overridden and not args.no_fast_extra:
         # secondary figure (not `value`): the same workload in the fp16-storage fast mode, the reference's GPU dtype
         del lmm
         torch.cuda.empty_cache()
@@ -454,7 +498,14 @@ def main(argv=None):
         log("DiT front-end pass done")
     if keep_sd:
         out["cpu_baseline"] = cpu_baseline(opt, sd, args.cpu_steps, args.points)
-        out["gpu_over_cpu"] = round(out["decode_only_tokens_per_s"] / out["cpu_baseline"]["value"], 1)
+        cb = out["cpu_baseline"]
+        out["gpu_over_cpu"] = {
+            "vs_sample_on_this_box": round(out["decode_only_tokens_per_s"] / cb["value"], 1),
+            "vs_full_run": round(out["value"] / cb["full_run"]["end_to_end_tokens_per_s"], 1) if cb.get("full_run") else None,
+            "note": "vs_sample_on_this_box = GPU decode-only rate over the full run / CPU decode rate of the bounded sample at contexts "
+                    "2050..2170 (THIS box's host cores: conservative, the CPU slows down as the context grows); vs_full_run = `value` "
+                    "(encode + prefill + 4000-token decode) / the committed full three-phase CPU run (build container, 8 threads). "
+                    "A GPU/CPU ratio says nothing about kernel quality - the roofline fraction does."}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -102,6 +102,7 @@ struct er_ctx {
     GenState st{};
     DecodeParamsDev* d_params = nullptr;
     int* d_ids_tmp = nullptr;
+    unsigned int* d_row_stream = nullptr;   // [B] Philox stream id per row (identity until er_set_row_streams)
     long long* d_out_ids = nullptr;   // [B][Lcap] generated ids (graph writes here; copied to the caller at the end)
     int* h_pinned = nullptr;      // small pinned host buffer
     int base_pos = 0;             // prefill length of the current generation
@@ -254,6 +255,8 @@ static void free_kv(er_ctx* c) {
     if (c->state_block) hipFree(c->state_block);
     if (c->d_params) hipFree(c->d_params);
     if (c->d_ids_tmp) hipFree(c->d_ids_tmp);
+    if (c->d_row_stream) hipFree(c->d_row_stream);
+    c->d_row_stream = nullptr;
     if (c->d_out_ids) hipFree(c->d_out_ids);
     c->d_out_ids = nullptr;
     c->state_block = nullptr; c->d_params = nullptr; c->d_ids_tmp = nullptr;
@@ -617,6 +620,13 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     c->st.unfinished = sb + 4 * b; c->st.eos_step = sb + 5 * b; c->st.base_pos = sb + 6 * b; c->st.n_unfinished = sb + 7 * b; c->st.error = sb + 7 * b + 1;
     HIPCHK(hipMalloc(&c->d_params, sizeof(DecodeParamsDev)));
     HIPCHK(hipMalloc(&c->d_ids_tmp, b * sizeof(int)));
+    HIPCHK(hipMalloc(&c->d_row_stream, b * sizeof(unsigned int)));
+    {
+        std::vector<unsigned int> ident(b);
+        for (size_t i = 0; i < b; ++i) ident[i] = (unsigned int)i;
+        HIPCHK(hipMemcpy(c->d_row_stream, ident.data(), b * sizeof(unsigned int), hipMemcpyHostToDevice));
+    }
+    c->st.row_stream = c->d_row_stream;
     HIPCHK(hipMalloc(&c->d_out_ids, b * (size_t)Lcap * sizeof(long long)));
     c->B = batch;
     c->Lcap = Lcap;
@@ -1254,6 +1264,18 @@ extern "C" int er_decode(er_ctx* c, const er_decode_params* p, int64_t* out_ids,
     }
     *n_steps = finished ? last + 1 : T;
     if (!finished && steps_run < T) return fail(ER_ERR_INVALID, "internal: stopped early with unfinished rows");
+    return ER_OK;
+}
+
+extern "C" int er_set_row_streams(er_ctx* c, const uint32_t* ids, int n) {
+    if (!c) return fail(ER_ERR_INVALID, "er_set_row_streams: null context");
+    if (c->B <= 0) return fail(ER_ERR_INVALID, "er_set_row_streams: no cache reserved (call er_kv_reserve)");
+    if (ids && n != c->B) return fail(ER_ERR_INVALID, "er_set_row_streams: %d ids for a batch of %d rows", n, c->B);
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<unsigned int> h((size_t)c->B);
+    for (int i = 0; i < c->B; ++i) h[i] = ids ? ids[i] : (unsigned int)i;
+    HIPCHK(hipDeviceSynchronize());           // a running decode still reads the old ids
+    HIPCHK(hipMemcpy(c->d_row_stream, h.data(), h.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
     return ER_OK;
 }
 

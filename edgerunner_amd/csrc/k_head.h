@@ -34,6 +34,9 @@ struct GenState {              // per-row arrays, all device
     int* base_pos;             // prefill length (position of the first generated token's forward)
     int* n_unfinished;         // scalar: rows still running
     int* error;                // scalar: set when a row had no finite candidate score (non-finite logits)
+    const unsigned int* row_stream;   // per row: second Philox counter word of the sampler (null: the row index).  A caller that
+                               // shards / batches independent jobs sets it to the GLOBAL job index, so a job's draws do not
+                               // depend on which rows share its batch (er_set_row_streams)
 };
 
 // Philox4x32-10 (Salmon et al. 2011): counter-based, so a draw is a pure function of
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(ER_WG) void sample_head_kernel(const float* logits,
                 float total = 0.f;
                 for (int c = 0; c < base; ++c) total += cand_e[c];
                 unsigned int r[4];
-                philox4x32_10((unsigned int)t, (unsigned int)b, 0u, 0u, P.seed_lo, P.seed_hi, r);
+                philox4x32_10((unsigned int)t, st.row_stream ? st.row_stream[b] : (unsigned int)b, 0u, 0u, P.seed_lo, P.seed_hi, r);
                 const float u = (float)(r[0] >> 8) * (1.0f / 16777216.0f);
                 const float target = u * total;
                 float acc = 0.f;

@@ -100,6 +100,14 @@ class LMM:
             raise native.NativeError(f"load_state_dict(strict=True): missing {missing[:5]}, unexpected {unexpected[:5]}")
         return missing, unexpected
 
+    def release_checkpoint(self):
+        """Drop the retained state_dict references (a full ArAE checkpoint is ~2.7 GB of host memory per rank) once the native
+        context holds the weights.  ``.half()`` / ``.float()`` can no longer re-store them afterwards and fail loudly."""
+        _ = self.mesh_decoder                  # make sure everything retained so far is on the device
+        self._sources.clear()
+        self._dec.direct_loads = True
+        return self
+
     def _cast(self, dtype):
         if dtype == self._dtype:
             return self
@@ -148,7 +156,7 @@ class LMM:
     # -- generation ---------------------------------------------------------------------------
     @torch.no_grad()
     def generate_ids(self, conds, num_faces=1000, resume_ids=None, tokenizer=None, max_new_tokens=None,
-                     min_new_tokens: int = 0, seed: Optional[int] = None) -> torch.Tensor:
+                     min_new_tokens: int = 0, seed: Optional[int] = None, row_streams=None) -> torch.Tensor:
         """Everything of LMM.generate up to the HF call's return value (core/models.py:215-303)."""
         opt = self.opt
         B = conds.shape[0]
@@ -169,7 +177,7 @@ class LMM:
             num_tokens = torch.full((B,), num_faces * 4 + opt.num_cond_tokens, dtype=torch.long)
         kwargs = dict(inputs_embeds=inputs_embeds, num_tokens=num_tokens, pad_token_id=opt.pad_token_id,
                       bos_token_id=opt.bos_token_id, eos_token_id=opt.eos_token_id, max_new_tokens=max_new_tokens,
-                      prefix_allowed_tokens_fn=fn, min_new_tokens=min_new_tokens, seed=seed)
+                      prefix_allowed_tokens_fn=fn, min_new_tokens=min_new_tokens, seed=seed, row_streams=row_streams)
         if opt.generate_mode == "greedy":
             kwargs["num_beams"] = 1
         elif opt.generate_mode == "sample":
@@ -179,11 +187,11 @@ class LMM:
 
     @torch.no_grad()
     def generate(self, conds, num_faces=1000, resume_ids=None, tokenizer=None, max_new_tokens=None, clean=True,
-                 min_new_tokens: int = 0, seed: Optional[int] = None):
+                 min_new_tokens: int = 0, seed: Optional[int] = None, row_streams=None):
         """-> (meshes, all_tokens) like core/models.py:204-319.  ``tokenizer`` is a
         ``edgerunner_amd.meto.Engine`` (or None for the 9-coordinate layout); each mesh is a
         ``(vertices, faces)`` pair (the reference returns trimesh objects, absent here)."""
-        output_ids = self.generate_ids(conds, num_faces, resume_ids, tokenizer, max_new_tokens, min_new_tokens, seed)
+        output_ids = self.generate_ids(conds, num_faces, resume_ids, tokenizer, max_new_tokens, min_new_tokens, seed, row_streams)
         from .meto import Engine, save_mesh
         meshes: List[Optional[object]] = []
         all_tokens: List[np.ndarray] = []

@@ -48,6 +48,7 @@ class MDiT:
         self.lib = native.load_library()
         self._ctx_h = C.c_void_p()
         self._sources = []                 # (state_dict reference, strict): replayed when .half()/.float() re-creates the context
+        self._released = False
         self.stream = torch.cuda.Stream(device=self.device)
         if precision is not None:
             self._materialize()
@@ -85,11 +86,36 @@ class MDiT:
             pass
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
-        """The dict is kept by reference so that .half() / .float() can rebuild the context in the other precision."""
+        """The dict is kept by reference so that .half() / .float() can rebuild the context in the other precision.
+        Returns (missing, unexpected); with ``strict`` a mismatch raises HERE, also while the context is not created yet
+        (module style): the expected keys are known from the options alone."""
+        if self._released:
+            raise native.NativeError("MDiT.load_state_dict after release_checkpoint(): create a new MDiT")
         self._sources.append((sd, strict))
         if self._ctx_h:
             return self._load_now(sd, strict)
-        return [], []
+        from .weights import clip_tensor_specs, dit_tensor_specs
+        want = {k for k, _, _ in dit_tensor_specs(self.opt)}
+        if self.clip_layers > 0:
+            want |= {k for k, _, _ in clip_tensor_specs(self.clip_layers)}
+        def norm(k):                           # transformers >= 5 drops the "vision_model." level (er_dit.h accepts both)
+            if k.startswith("image_encoder.") and not k.startswith("image_encoder.vision_model."):
+                return "image_encoder.vision_model." + k[len("image_encoder."):]
+            return k
+        have = set()
+        for src, _ in self._sources:           # several partial dicts (denoiser, image encoder) add up
+            have |= {norm(k) for k, t in src.items() if isinstance(t, torch.Tensor)}
+        missing, unexpected = sorted(want - have), sorted({k for k in sd if norm(k) not in want})
+        if strict and unexpected:
+            raise native.NativeError(f"MDiT.load_state_dict(strict=True): unexpected {unexpected[:5]}")
+        return missing, unexpected
+
+    def release_checkpoint(self):
+        """Drop the retained state_dict references once the native context holds the weights (see LMM.release_checkpoint)."""
+        _ = self._ctx
+        self._sources.clear()
+        self._released = True
+        return self
 
     def _load_now(self, sd, strict):
         unexpected = []
@@ -108,6 +134,8 @@ class MDiT:
         return missing, unexpected
 
     def _cast(self, fp16: bool):
+        if fp16 != self._fp16 and self._released:
+            raise native.NativeError("MDiT.half()/float() after release_checkpoint(): the weights cannot be re-stored")
         if fp16 != self._fp16:
             self._fp16 = fp16
             self.close()                   # rebuilt on next use from the retained checkpoints

@@ -27,7 +27,7 @@ EXPORTS = [
     "er_kv_reserve", "er_encode_cond", "er_embed_tokens", "er_prefill", "er_logits", "er_feed", "er_decode",
     "er_meto_decode", "er_meto_encode", "er_dit_create", "er_dit_destroy", "er_dit_load_tensor",
     "er_dit_finalize_weights", "er_dit_project_cond", "er_dit_encode_image", "er_dit_forward", "er_dit_sample",
-    "er_plan_decode", "er_ctx_plan", "er_plan_gemm_tile", "er_kernel_kind_name", "er_profile_decode_kernels", "er_profile_decode_kernels_at", "er_last_decode_ms",
+    "er_set_row_streams", "er_plan_decode", "er_ctx_plan", "er_plan_gemm_tile", "er_kernel_kind_name", "er_profile_decode_kernels", "er_profile_decode_kernels_at", "er_last_decode_ms",
     "er_k_gemv", "er_k_attn_decode", "er_k_attn_outproj3", "er_k_gemm", "er_k_gemm_f16", "er_k_gemm_f16s", "er_k_flash_attn_f16", "er_k_flash_attn_f32", "er_k_flash_attn_f16s", "er_k_layernorm", "er_k_softmax", "er_k_sample_head",
 ]
 
@@ -108,6 +108,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.er_dit_sample.argtypes = [vp, vp, ci, ci, vp, ci, cf, ci, vp]
     lib.er_plan_decode.argtypes = [ci, ci, ci, ci, ci, C.POINTER(ErDecodePlan)]
     lib.er_ctx_plan.argtypes = [vp, C.POINTER(ErDecodePlan)]
+    lib.er_set_row_streams.argtypes = [vp, C.POINTER(C.c_uint32), ci]
     lib.er_plan_gemm_tile.argtypes = [ci, ci, ci]
     lib.er_k_gemv.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp]
     lib.er_k_attn_decode.argtypes = [vp, vp, vp, C.POINTER(C.c_int32), vp, ci, ci, ci, ci, ci, ci, ci, vp]

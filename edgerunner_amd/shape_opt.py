@@ -191,7 +191,8 @@ class NativeShapeOPT:
     def generate(self, inputs_embeds: torch.Tensor, num_tokens=None, pad_token_id=None, bos_token_id=None,
                  eos_token_id=None, max_new_tokens: Optional[int] = None,
                  prefix_allowed_tokens_fn: Optional[Callable] = None, num_beams: int = 1, do_sample: bool = False,
-                 top_k: int = 50, min_new_tokens: int = 0, seed: Optional[int] = None, **unused) -> torch.Tensor:
+                 top_k: int = 50, min_new_tokens: int = 0, seed: Optional[int] = None, row_streams=None,
+                 **unused) -> torch.Tensor:
         """Drop-in for ``ShapeOPT.generate`` as called at core/models.py:303.
         ``num_tokens`` is accepted and ignored exactly like the reference decoder
         ignores it (modeling_opt.py:324,467,546)."""
@@ -205,6 +206,11 @@ class NativeShapeOPT:
             max_new_tokens = self.opt.max_seq_length
         B = inputs_embeds.shape[0]
         self.prefill(inputs_embeds, max_new_tokens)
+        # sample mode: the Philox stream of row b (default b; a sharding / batching caller passes global job indices)
+        if row_streams is not None and len(row_streams) != B:
+            raise ValueError(f"row_streams has {len(row_streams)} entries for a batch of {B}")
+        arr = None if row_streams is None else (C.c_uint32 * B)(*[int(v) & 0xFFFFFFFF for v in row_streams])
+        native.check(self.lib.er_set_row_streams(self._ctx, arr, B), "er_set_row_streams")
         if prefix_allowed_tokens_fn is None or isinstance(prefix_allowed_tokens_fn, BuiltinGrammar):
             grammar = native.ER_GRAMMAR_NONE if prefix_allowed_tokens_fn is None else prefix_allowed_tokens_fn.er_grammar
             return self._decode_device(B, max_new_tokens, min_new_tokens, do_sample, top_k, grammar, seed)

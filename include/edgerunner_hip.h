@@ -140,6 +140,12 @@ int er_feed(er_ctx* ctx, const int32_t* ids_host, void* stream);
  * Blocks until the result is complete. */
 int er_decode(er_ctx* ctx, const er_decode_params* p, int64_t* out_ids_dev,
               int32_t* n_steps_host, void* stream);
+/* Sample mode draws are Philox4x32-10(key = seed, counter = (step, stream id of the row)).  The stream id of row b is b until this
+ * call sets it (ids_host: n = reserved batch entries; NULL restores the identity).  A caller that shards or batches the reference's
+ * serial loop (infer.py:99-101: file x test_repeat x test_num_face) passes the GLOBAL job index of every row, so a job's tokens do
+ * not depend on the world size or on which jobs share its batch (torch.multinomial's global generator gives the reference the
+ * same property for its serial loop). */
+int er_set_row_streams(er_ctx* ctx, const uint32_t* ids_host, int n);
 
 /* ---- mesh tokenizer (host code, no device work): the reference's pybind11 module meto (meto/src/bindings.cpp,
  * meto.Engine(discrete_bins, verbose, backend), meto/meto/__init__.py:21-54) for the backends Options.meto_backend

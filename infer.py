@@ -7,10 +7,17 @@
 Same flags (``edgerunner_amd.options`` mirrors ``core/options.py``), same outputs
 (``{name}_{i}_{n}f_tokens.npy`` = ids-3 cut at EOS, ``{name}_pc.obj``; reference infer.py:86-123).
 Inputs: .obj/.ply meshes (surface-sampled to ``point_num`` points) or .npy point clouds [N,3].
+``--cond_mode none`` (reference infer.py:96-97) generates from the face-count token alone, once per input path.
 With torchrun (one process per GPU) the (file x repeat x num_face) jobs are sharded block-cyclically over ranks;
 inside a rank, jobs with the same face count run as ONE batched generate() call (the B > 1 decode path streams the
 weights once for all rows), and the generated token streams are all-gathered over RCCL at the end
 (``{workspace}/tokens_all.npz`` on rank 0).
+
+Reproducibility: in sample mode job j (its index in the reference's loop order) draws from the Philox stream
+(--seed, step, j), whatever the world size, ER_INFER_BATCH or free memory made of the grouping.  In the fp16 (default) precision
+the projections of calls with more than 4 rows run on the matrix cores and round differently from the 1..4-row kernels
+(both within 1e-5 of the fp16-storage model), so a near-tie can still resolve differently when the grouping changes;
+EDGERUNNER_PRECISION=fp32 with ER_INFER_BATCH <= 4 (or any fixed grouping) is bit-reproducible.
 """
 from __future__ import annotations
 
@@ -37,6 +44,8 @@ from edgerunner_amd.utils import seed_everything, trim_tokens  # noqa: E402
 def load_points(opt, path):
     """One cloud per input path, reused for every repeat and face count (reference infer.py:84-92).  The surface
     sampler is seeded by (opt.seed, path) so that every rank - and a world-size-1 run - derives the same cloud."""
+    if opt.cond_mode == "none":                      # reference infer.py:96-97: a [1, 0] dummy that only carries the batch size
+        return np.zeros((0, 3), dtype=np.float32)
     if path.endswith(".npy"):
         return np.load(path).astype(np.float32).reshape(-1, 3)
     rng = np.random.default_rng([int(opt.seed) & 0xFFFFFFFF, zlib.crc32(os.path.basename(path).encode())])
@@ -46,24 +55,36 @@ def load_points(opt, path):
 
 
 def max_rows_per_call(opt, model, max_new_tokens, device) -> int:
-    """How many independent jobs one generate() call may carry: bounded by the KV cache (+ prefill scratch) that fits
-    in half of the free HBM, by 32 (one pass of the batched projections) and by ER_INFER_BATCH."""
+    """How many independent jobs one generate() call carries: ER_INFER_BATCH (default 32 = one pass of the batched
+    projections) - a fixed number, so the grouping does not depend on what else occupies the device.  Memory is only a guard:
+    the rows' KV cache + prefill / encoder scratch must fit in the HBM that is free once the weights are resident (the native
+    context is created here, before the measurement)."""
     d = model.dims
     esz = 2 if model.precision == "fp16" else 4
     l_cap = d.num_cond_tokens + 2 + max_new_tokens
     kv_row = 2 * d.num_layers * d.hidden_dim * esz * l_cap
     scratch_row = (d.num_cond_tokens + 1) * (6 * d.hidden_dim + d.intermediate_dim) * 4
-    free, _ = torch.cuda.mem_get_info(device)
-    cap = int(os.environ.get("ER_INFER_BATCH", "32"))
-    return max(1, min(cap, int(0.5 * free // (kv_row + scratch_row))))
+    if d.cond_mode == "point":                       # encoder scratch per sample at point_num points (K / V / x rows + the GEGLU buffers)
+        scratch_row += (3 * opt.point_num + 14 * d.point_latent_size) * d.point_hidden_dim * 4
+    _ = model.mesh_decoder                           # materialise the context: the weights are on the device from here on
+    free, _total = torch.cuda.mem_get_info(device)
+    cap = max(1, int(os.environ.get("ER_INFER_BATCH", "32")))
+    fit = int(0.8 * free // (kv_row + scratch_row))
+    if fit < 1:
+        raise SystemExit(f"[ERROR] not enough free HBM for one job: {free / 2**30:.1f} GiB free, one row needs "
+                         f"{(kv_row + scratch_row) / 2**30:.1f} GiB (lower --test_max_seq_length)")
+    if fit < cap:
+        print(f"[WARN] {free / 2**30:.1f} GiB free: {fit} jobs per call instead of {cap} (sample-mode results are unaffected, "
+              "fp16 greedy near-ties may resolve differently - see the module docstring)")
+    return min(cap, fit)
 
 
 def main(argv=None):
     opt = parse_cli(argv)
     rank, world, local = D.init_process_group()
     seed_everything(opt.seed)
-    if opt.cond_mode != "point":
-        raise SystemExit("this build serves cond_mode='point' (ArAE preset); see infer_dit for point_latent")
+    if opt.cond_mode not in ("point", "none"):
+        raise SystemExit("infer.py serves cond_mode='point' (ArAE preset) and 'none'; see infer_dit.py for the image -> point_latent path")
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: this path has no CPU fallback")
     device = torch.device("cuda", local)
@@ -87,6 +108,8 @@ def main(argv=None):
         model = model.float().eval().to(device)
     else:
         model = model.half().eval().to(device)
+    model.release_checkpoint()        # the weights are on the device in their final precision: drop the host copy (~2.7 GB per rank)
+    ckpt = None
 
     tokenizer, _ = get_tokenizer(opt)
 
@@ -102,7 +125,7 @@ def main(argv=None):
         if path not in clouds:
             clouds[path] = load_points(opt, path)
     for path in paths:                               # exactly one rank exports the cloud of a path
-        if pc_owner[path] == rank:
+        if pc_owner[path] == rank and opt.cond_mode == "point":
             if path not in clouds:
                 clouds[path] = load_points(opt, path)
             name = os.path.splitext(os.path.basename(path))[0]
@@ -112,8 +135,9 @@ def main(argv=None):
     for num_faces, chunk in D.group_jobs(jobs, mine, lambda p: clouds[p].shape[0], rows_max):
         cond = torch.from_numpy(np.stack([clouds[jobs[j][0]] for j in chunk])).float().to(device)
         t0 = time.time()
+        # sample mode: job j draws from the Philox stream (opt.seed, step, j) whatever rows share its call
         meshes, tokens = model.generate(cond, num_faces=num_faces, max_new_tokens=opt.test_max_seq_length,
-                                        tokenizer=tokenizer, clean=True, seed=opt.seed + 7919 * chunk[0])
+                                        tokenizer=tokenizer, clean=True, seed=opt.seed, row_streams=list(chunk))
         torch.cuda.synchronize()
         dt = time.time() - t0
         for r, j in enumerate(chunk):

@@ -85,6 +85,9 @@ def main(argv=None):
         model, model_dit = model.float().eval().to(device), model_dit.float().eval().to(device)
     else:
         model, model_dit = model.half().eval().to(device), model_dit.half().eval().to(device)
+    # the weights are on the device in their final precision: drop the host copies of both checkpoints
+    model.release_checkpoint()
+    model_dit.release_checkpoint()
     dit_steps = int(os.environ.get("ER_DIT_STEPS", "100"))         # test knob: MDiT.run's default is 100 (models_dit.py:187)
     tokenizer, _ = get_tokenizer(opt)
 

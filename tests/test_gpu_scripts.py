@@ -92,6 +92,54 @@ def test_infer_py_batched_jobs_half_and_float(arae_ckpt, tmp_path):
     assert len({tuple(x.tolist()) for x in r[0]}) > 1, "test_repeat samples must differ"
 
 
+def test_infer_py_sample_mode_does_not_depend_on_job_grouping(arae_ckpt, tmp_path):
+    """a job's sampled tokens are a function of (--seed, job index) only - the Philox stream id of a row is the
+    job's index in the reference's loop order (infer.py:99-101), not its position in whatever batch it landed in.  Exact
+    mode, so the batched and the single-row kernels agree bit for bit: one job per call vs all six jobs in one call."""
+    from edgerunner_amd import weights as W
+    opt, sd, ckpt = arae_ckpt
+    inp = tmp_path / "a.npy"
+    np.save(inp, W.synthetic_point_cloud(0, 512)[0].numpy())
+    runs = {}
+    for name, nb in (("one", "1"), ("three", "3"), ("all", "32")):
+        out = tmp_path / f"out_{name}"
+        log = run_script("infer.py", ["ArAE", "--num_layers", 2, "--resume", ckpt, "--test_path", inp, "--generate_mode", "sample",
+                                      "--test_num_face", 1000, 4000, "--test_repeat", 3, "--test_max_seq_length", 48, "--seed", 9,
+                                      "--workspace", out], {"EDGERUNNER_PRECISION": "fp32", "ER_INFER_BATCH": nb})
+        assert ("(1 jobs in this call)" in log) == (nb == "1"), log[-1500:]
+        runs[name] = {k: v for k, v in np.load(out / "tokens_all.npz").items()}
+    assert len(runs["one"]) == 6
+    for k, v in runs["one"].items():
+        assert np.array_equal(v, runs["three"][k]) and np.array_equal(v, runs["all"][k]), k
+    assert len({tuple(v.tolist()) for v in runs["one"].values()}) > 3, "six jobs, six Philox streams"
+
+
+def test_infer_py_cond_mode_none(tmp_path):
+    """reference infer.py:96-97 / core/models.py:131-141: cond_mode='none' generates from the face-count token alone
+    (num_cond_tokens = 1), once per input path; ids == the CPU oracle."""
+    import arae_oracle as O
+    from safetensors.torch import save_file
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.options import config_defaults
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=2, generate_mode="greedy", cond_mode="none", num_cond_tokens=1)
+    sd = W.make_state_dict(opt, 0, "perturbed")
+    assert not any(k.startswith(("point_encoder.", "proj_cond.")) for k in sd)
+    ckpt = str(tmp_path / "none.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, ckpt)
+    (tmp_path / "inputs").mkdir()
+    for n in ("x", "y"):
+        np.save(tmp_path / "inputs" / f"{n}.npy", np.zeros((4, 3), np.float32))      # the path only names the outputs
+    out = tmp_path / "out"
+    run_script("infer.py", ["ArAE", "--num_layers", 2, "--cond_mode", "none", "--num_cond_tokens", 1, "--resume", ckpt,
+                            "--test_path", tmp_path / "inputs", "--generate_mode", "greedy", "--test_num_face", 1000, 8000,
+                            "--test_max_seq_length", 40, "--workspace", out], {"EDGERUNNER_PRECISION": "fp32"})
+    for nf in (1000, 8000):
+        want = trimmed(O.lmm_generate_ids(sd, opt, torch.zeros(1, 0), nf, max_new_tokens=40).numpy()[0])
+        for n in ("x", "y"):
+            assert np.array_equal(np.load(out / f"{n}_0_{nf}f_tokens.npy"), want), (n, nf)
+        assert not (out / "x_pc.obj").exists()
+
+
 def test_lmm_half_selects_fp16_context_or_fails_loudly(arae_ckpt):
     from edgerunner_amd import native
     from edgerunner_amd.models import LMM
