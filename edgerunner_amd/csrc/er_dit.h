@@ -10,6 +10,10 @@ struct DitLayerW {
     float *q2_w = nullptr, *q2_b = nullptr, *k2_w = nullptr, *k2_b = nullptr, *v2_w = nullptr, *v2_b = nullptr,
           *o2_w = nullptr, *o2_b = nullptr;                                                      // attn2 (cross)
     float *ff0_w = nullptr, *ff0_b = nullptr, *ff2_w = nullptr, *ff2_b = nullptr;
+    // fp16 mode: ff0 with its rows permuted so that the GEMM epilogue sees value and gate of an output in one wave (k_gemm.h,
+    // HEPI_GEGLU); built on first use from the fp16 copy of ff0_w
+    _Float16* ff0_p16 = nullptr;
+    float* ff0_bp = nullptr;
 };
 
 struct ClipLayerW {
@@ -37,6 +41,9 @@ struct er_dit_ctx {
     bool fast = false;                                   // fp16-input MFMA for every Linear (weights stored fp16 too)
     std::map<const float*, const _Float16*> half_of;     // fp32 weight block -> its fp16 copy
     Buf x, qkv, att, q2, kv2, u, g, sc, tin, temb0, temb1, temb, tsil, tada, gate, t_dev, xin, pred, czero, ctmp;
+    // fp16 mode: fp16 copies of the activations that feed a Linear, written by their producers (k_gemm.h, gemm_hh_mfma_kernel)
+    Buf x16, att16, g16;
+    bool geglu_perm_valid = false;
 };
 
 static void dit_register(er_dit_ctx* c) {
@@ -126,7 +133,7 @@ extern "C" int er_dit_destroy(er_dit_ctx* c) {
     for (Buf* b : {&c->cpx, &c->ccol, &c->cpatch, &c->cx, &c->ch, &c->cq, &c->ck, &c->cv, &c->catt, &c->cf})
         if (b->p) hipFree(b->p);
     for (Buf* b : {&c->x, &c->qkv, &c->att, &c->q2, &c->kv2, &c->u, &c->g, &c->sc, &c->tin, &c->temb0, &c->temb1, &c->temb,
-                   &c->tsil, &c->tada, &c->gate, &c->t_dev, &c->xin, &c->pred, &c->czero, &c->ctmp})
+                   &c->tsil, &c->tada, &c->gate, &c->t_dev, &c->xin, &c->pred, &c->czero, &c->ctmp, &c->x16, &c->att16, &c->g16})
         if (b->p) hipFree(b->p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -172,6 +179,7 @@ extern "C" int er_dit_load_tensor(er_dit_ctx* c, const char* key, const void* da
     }
     HIPCHK(hipMemcpy(*it->second.p, h.data(), n * 4, hipMemcpyHostToDevice));
     it->second.loaded = true;
+    c->geglu_perm_valid = false;          // any reload invalidates the permuted feed-forward operands
     return ER_OK;
 }
 
@@ -262,10 +270,45 @@ extern "C" int er_dit_encode_image(er_dit_ctx* c, const float* images, int B, in
 }
 
 static hipError_t dit_ln_mod(const float* x, float* y, int rows, int rows_per_batch, const float* table, const float* tvec,
-                             long long t_bstride, long long t_cstride, int shift_idx, int scale_idx, hipStream_t st) {
+                             long long t_bstride, long long t_cstride, int shift_idx, int scale_idx, hipStream_t st,
+                             _Float16* y16 = nullptr) {
     hipLaunchKernelGGL((ln_modulate_rows_kernel<16>), dim3((rows + ER_NWAVES - 1) / ER_NWAVES), dim3(ER_WG), 0, st, x, y, rows,
-                       rows_per_batch, table, tvec, t_bstride, t_cstride, shift_idx, scale_idx, 1e-6f);
+                       rows_per_batch, table, tvec, t_bstride, t_cstride, shift_idx, scale_idx, 1e-6f, y16);
     return hipGetLastError();
+}
+
+// fp16 mode: permuted ff0 operands of every layer (once per set of weights)
+static int dit_build_geglu_perm(er_dit_ctx* c, hipStream_t st) {
+    if (c->geglu_perm_valid) return 0;
+    const int C = c->cfg.hidden_dim, F = 4 * C;
+    for (auto& L : c->layers) {
+        auto it = c->half_of.find(L.ff0_w);
+        if (it == c->half_of.end()) return fail(ER_ERR_INVALID, "dit: no fp16 copy of ff.net.0.proj");
+        if (!L.ff0_p16) {
+            HIPCHK(hipMalloc((void**)&L.ff0_p16, (size_t)2 * F * C * sizeof(_Float16)));
+            c->owned.push_back(L.ff0_p16);
+            HIPCHK(hipMalloc((void**)&L.ff0_bp, (size_t)2 * F * sizeof(float)));
+            c->owned.push_back(L.ff0_bp);
+        }
+        hipLaunchKernelGGL(geglu_permute_kernel, dim3(2 * F), dim3(ER_WG), 0, st, it->second, L.ff0_b, L.ff0_p16, L.ff0_bp, F, C);
+        HIPRET(hipGetLastError());
+    }
+    c->geglu_perm_valid = true;
+    return 0;
+}
+
+// fp16 mode, A already in fp16 (written by its producer): both operands by LDS-DMA.  c16: optional fp16 copy of the output.
+static hipError_t dlin16(er_dit_ctx* c, const _Float16* A16, int lda, const float* W, const float* bias, float* C, int ldc, int M,
+                         int N, int K, const float* resid, int ldr, const float* gate, int gate_rows, _Float16* c16, hipStream_t st) {
+    GemmArgs g = gemm_args_default();
+    g.A = reinterpret_cast<const float*>(A16); g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldr;
+    g.gate = gate; g.gate_rows = gate_rows; g.gate_bstride = N;
+    g.c16 = c16; g.ldc16 = N;
+    auto it = c->half_of.find(W);
+    if (it == c->half_of.end()) return hipErrorInvalidValue;
+    g.B = reinterpret_cast<const float*>(it->second);
+    return launch_gemm_hh(g, st);
 }
 
 // t_emb / t_adaln for B rows with timesteps already on the device (t_dev [B])
@@ -322,6 +365,17 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     const bool flash = c->fast && D == FA_D && !no_flash;
     if (!flash) ERCHK(ensure(c->sc, (size_t)H * N * ldS));
     ERCHK(ensure(c->gate, (size_t)B * C));
+    // fp16 activations for the LDS-DMA GEMM (all K of this path are multiples of 64 except none: C = 1024, 4C = 4096)
+    const bool hh = flash && C % 64 == 0;
+    if (hh) {
+        ERCHK(ensure(c->x16, (size_t)R * C / 2 + 8));
+        ERCHK(ensure(c->att16, (size_t)R * C / 2 + 8));
+        ERCHK(ensure(c->g16, (size_t)R * 4 * C / 2 + 8));
+    }
+    _Float16* x16 = hh ? reinterpret_cast<_Float16*>(c->x16.p) : nullptr;
+    _Float16* att16 = hh ? reinterpret_cast<_Float16*>(c->att16.p) : nullptr;
+    _Float16* g16 = hh ? reinterpret_cast<_Float16*>(c->g16.p) : nullptr;
+    if (hh) ERCHK(dit_build_geglu_perm(c, st));
     ERCHK(dit_time_embed(c, B, st));
     float* x = c->x.p;
     // x = proj_in(x) + pos_embed                                                  dit.py:177-180
@@ -331,15 +385,17 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     for (int l = 0; l < g.num_layers; ++l) {
         const DitLayerW& L = c->layers[l];
         // x = norm1(x) * (1 + scale_msa) + shift_msa   (chunks 0 = shift, 1 = scale, 2 = gate)     dit.py:129-132
-        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st));
+        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st, x16));
         // x = x + gate_msa * attn1(x)                                               dit.py:133
-        HIPRET(dlin(c, x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, st));
+        if (hh) HIPRET(dlin16(c, x16, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, nullptr, st));
+        else HIPRET(dlin(c, x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, st));
         if (flash) {
             FlashArgs fa{};
             fa.Q = c->qkv.p; fa.K = c->qkv.p + C; fa.V = c->qkv.p + 2 * C; fa.O = c->att.p; fa.N = N; fa.M = N;
             fa.ldq = fa.ldk = fa.ldv = 3 * C; fa.ldo = C;
             fa.qs_b = fa.ks_b = fa.vs_b = (long long)N * 3 * C; fa.os_b = (long long)N * C;
             fa.head_stride = D; fa.scale = 1.0f / sqrtf((float)D);
+            fa.O16 = att16;
             HIPRET(launch_flash_attn_f16(fa, H, B, st));
         } else {
             for (int b = 0; b < B; ++b) {
@@ -350,9 +406,12 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         }
         hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 2);
         HIPRET(hipGetLastError());
-        HIPRET(dlin(c, c->att.p, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, st));
+        // (the fp16 copy of the new x is the A operand of the cross-attention query projection)
+        if (hh) HIPRET(dlin16(c, att16, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, x16, st));
+        else HIPRET(dlin(c, c->att.p, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, st));
         // x = x + attn2(x, c)                                                       dit.py:135
-        HIPRET(dlin(c, x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, st));
+        if (hh) HIPRET(dlin16(c, x16, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, nullptr, st));
+        else HIPRET(dlin(c, x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, st));
         const float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
         const float* v2 = k2 + (size_t)B * M * C;
         if (flash) {
@@ -361,25 +420,36 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
             fa.ldq = fa.ldk = fa.ldv = fa.ldo = C;
             fa.qs_b = fa.os_b = (long long)N * C; fa.ks_b = fa.vs_b = (long long)M * C;
             fa.head_stride = D; fa.scale = 1.0f / sqrtf((float)D);
+            fa.O16 = att16;
             HIPRET(launch_flash_attn_f16(fa, H, B, st));
         } else {
             for (int b = 0; b < B; ++b)
                 ERCHK(attention_full(c->q2.p + (size_t)b * N * C, C, k2 + (size_t)b * M * C, C, D, v2 + (size_t)b * M * C, C, D,
                                      c->att.p + (size_t)b * N * C, C, c->sc.p, H, D, N, M, false, st));
         }
-        HIPRET(dlin(c, c->att.p, C, L.o2_w, L.o2_b, x, C, R, C, C, x, C, nullptr, 1, st));
+        if (hh) HIPRET(dlin16(c, att16, C, L.o2_w, L.o2_b, x, C, R, C, C, x, C, nullptr, 1, nullptr, st));
+        else HIPRET(dlin(c, c->att.p, C, L.o2_w, L.o2_b, x, C, R, C, C, x, C, nullptr, 1, st));
         // x = norm2(x) * (1 + scale_mlp) + shift_mlp; x = x + gate_mlp * ff(x)     dit.py:137-139
-        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 3, 4, st));
-        HIPRET(dlin(c, x, C, L.ff0_w, L.ff0_b, c->u.p, 8 * C, R, 8 * C, C, nullptr, 0, nullptr, 1, st));
-        hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)R * 4 * C)), dim3(ER_WG), 0, st, c->u.p, c->g.p, (long long)R, 4 * C);
-        HIPRET(hipGetLastError());
+        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 3, 4, st, x16));
+        if (hh) {     // feed-forward in + GEGLU in one launch: the [R][8C] pre-activation never reaches HBM (dit.py FeedForward)
+            GemmArgs fg = gemm_args_default();
+            fg.A = reinterpret_cast<const float*>(x16); fg.B = reinterpret_cast<const float*>(L.ff0_p16); fg.bias = L.ff0_bp;
+            fg.M = R; fg.N = 8 * C; fg.K = C; fg.lda = C; fg.ldb = C; fg.c16 = g16; fg.ldc16 = 4 * C;
+            HIPRET(launch_gemm_hh_geglu(fg, st));
+        } else {
+            HIPRET(dlin(c, x, C, L.ff0_w, L.ff0_b, c->u.p, 8 * C, R, 8 * C, C, nullptr, 0, nullptr, 1, st));
+            hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)R * 4 * C)), dim3(ER_WG), 0, st, c->u.p, c->g.p, (long long)R, 4 * C);
+            HIPRET(hipGetLastError());
+        }
         hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 5);
         HIPRET(hipGetLastError());
-        HIPRET(dlin(c, c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, c->gate.p, N, st));
+        if (hh) HIPRET(dlin16(c, g16, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, c->gate.p, N, nullptr, st));
+        else HIPRET(dlin(c, c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, c->gate.p, N, st));
     }
     // shift, scale = scale_shift_table + t_emb; x = norm_out(x) * (1 + scale) + shift; proj_out     dit.py:190-194
-    HIPRET(dit_ln_mod(x, x, R, N, c->sst2, c->temb.p, (long long)C, 0, 0, 1, st));
-    HIPRET(dlin(c, x, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, nullptr, 0, nullptr, 1, st));
+    HIPRET(dit_ln_mod(x, x, R, N, c->sst2, c->temb.p, (long long)C, 0, 0, 1, st, x16));
+    if (hh) HIPRET(dlin16(c, x16, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, nullptr, 0, nullptr, 1, nullptr, st));
+    else HIPRET(dlin(c, x, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, nullptr, 0, nullptr, 1, st));
     return 0;
 }
 

@@ -9,11 +9,13 @@ namespace er {
 // with  scale_b[c] = table[scale_idx][c] + tvec[b*t_bstride + scale_idx*t_cstride + c]   (same for shift):
 //   DiTLayer: table = scale_shift_table [6][C], tvec = t_adaln [B][6][C]  (t_bstride 6C, t_cstride C)
 //   DiT out:  table = scale_shift_table [2][C], tvec = t_emb   [B][C]     (t_bstride C,  t_cstride 0)
-// One wave per row (row in registers).  In-place allowed.
+// One wave per row (row in registers).  In-place allowed.  y16 (optional): the same row rounded to fp16 - the A operand of the
+// Linear that follows (gemm_hh_mfma_kernel).
 template <int CPL>
 __global__ __launch_bounds__(ER_WG) void ln_modulate_rows_kernel(const float* x, float* y, int rows, int rows_per_batch,
                                                                  const float* table, const float* tvec, long long t_bstride,
-                                                                 long long t_cstride, int shift_idx, int scale_idx, float eps) {
+                                                                 long long t_cstride, int shift_idx, int scale_idx, float eps,
+                                                                 _Float16* y16) {
     constexpr int C = CPL * 64;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * ER_NWAVES + (threadIdx.x >> 6);
@@ -36,7 +38,9 @@ __global__ __launch_bounds__(ER_WG) void ln_modulate_rows_kernel(const float* x,
         const int c = lane + 64 * i;
         const float scale = table[scale_idx * C + c] + tb[scale_idx * t_cstride + c];
         const float shift = table[shift_idx * C + c] + tb[shift_idx * t_cstride + c];
-        yr[c] = (v[i] - mean) * rstd * (1.0f + scale) + shift;
+        const float o = (v[i] - mean) * rstd * (1.0f + scale) + shift;
+        yr[c] = o;
+        if (y16) y16[(long long)r * C + c] = (_Float16)o;
     }
 }
 

@@ -21,6 +21,7 @@ struct FlashArgs {
     long long qs_b, ks_b, vs_b, os_b;   // batch strides
     int head_stride;                // offset between heads inside a row (= D)
     float scale;                    // 1/sqrt(D)
+    _Float16* O16;                  // optional: the output rounded to fp16 INSTEAD of O (same strides): it only feeds an fp16 Linear
 };
 
 constexpr int FA_D = 64, FA_QW = 32, FA_KT = 64, FA_LD = 72;   // head dim, q rows per wave, keys per tile, LDS row stride (halves)
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f16_kernel(FlashArgs a) {
     const float* Q = a.Q + b * a.qs_b + h * a.head_stride;
     const float* K = a.K + b * a.ks_b + h * a.head_stride;
     const float* V = a.V + b * a.vs_b + h * a.head_stride;
-    float* O = a.O + b * a.os_b + h * a.head_stride;
+    float* O = a.O16 ? nullptr : a.O + b * a.os_b + h * a.head_stride;
+    _Float16* O16 = a.O16 ? a.O16 + b * a.os_b + h * a.head_stride : nullptr;
 
     // Q fragment (B operand of S^T): q = q0 + li, d = ks*16 + half*8 + e
     fa_h8 qb[4];
@@ -145,11 +147,15 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f16_kernel(FlashArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const int q = q0 + li;
     if (q < a.N) {
-        float* orow = O + (long long)q * a.ldo;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) orow[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = ot[db][r] / l_tot;
+            for (int r = 0; r < 16; ++r) {
+                const long long o = (long long)q * a.ldo + db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = ot[db][r] / l_tot;
+                if (O16) O16[o] = (_Float16)v;
+                else O[o] = v;
+            }
     }
 }
 

@@ -1,7 +1,6 @@
-// STAGED for round 3 (behind ER_PREFILL_ATTN_F16S=1, default off): the fast-mode prefill attention on the fp16 matrix
-// cores with fp32-grade operands.  Status at the end of round 2: the kernel's unit tests pass on the GPU (3e-6 vs float64,
-// tests/test_gpu_kernels.py::test_flash_attn_f16s_staged); NOT yet timed and not yet run through the end-to-end fast-mode
-// parity tests, hence not on the default path.
+// The fast-mode prefill attention on the fp16 matrix cores with fp32-grade operands: the default for batches of >= 2
+// prefixes (round 3: encode + prefill per sample 15.5 -> 13.4 ms at B = 8, 14.65 -> 12.65 ms at B = 32; at B = 1 it is 3 % slower
+// than the fp32 kernel and not used; end-to-end fast-mode logits move by 2.9e-6, profiles/r03_f16s_prefix_attention.log).
 //
 // In fast mode the K / V rows the prefix attention reads are already fp16 values (kv_scatter_half_kernel rounds them to
 // the cache dtype, er_api.hip), but the fused attention still runs on the fp32 matrix cores (flash_attn_f32_kernel: 7.4 of

@@ -43,6 +43,10 @@ struct GemmArgs {
     float* q; float* kcache; float* vcache;
     int S, hidden, head_dim, l_cap;
     long long kv_bstride;
+    // GEPI_PLAIN, optional: the same value rounded to fp16 into c16 [M][ldc16] - the A operand of the NEXT fp16 GEMM
+    // (gemm_hh_mfma_kernel reads fp16 activations straight into LDS), written by the kernel that produces it
+    _Float16* c16;
+    int ldc16;
 };
 
 constexpr int GBK = 32;
@@ -50,39 +54,73 @@ constexpr int GBK = 32;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // epilogue shared by the fp32 and fp16-input kernels: C/D fragment map of the 32x32 MFMA (dtype independent):
-// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Everything that depends on the column only (bias, the q/k/v split of GEPI_QKV) is resolved once per 32-column block, and the
+// row -> batch maps (adaLN gate row, shared residual table, cache row of GEPI_QKV) without a division per element: a wave's 32
+// rows cross at most one batch boundary when the batch has >= 32 rows (otherwise the generic division path runs).  Round 2
+// evaluated five integer divisions and every option per ELEMENT in a 64-fold unrolled body: ~100 KB of code per kernel, which the
+// instruction cache could not hold - a fixed ~19 us per workgroup, i.e. the whole time of a K = 1024 GEMM
+// (profiles/r03_gemm_hh_probe.log).
+struct RowBatch {          // batch index (row / period) and row inside the batch for the rows [row0, row0 + span) (span 32: one MFMA block)
+    int q0, next, period;
+    bool fast;
+    __device__ __forceinline__ RowBatch(int row0, int period_, int span = 32) : period(period_) {
+        fast = period_ >= span;
+        q0 = period_ > 0 ? row0 / period_ : 0;
+        next = (q0 + 1) * period_;
+    }
+    __device__ __forceinline__ int batch(int gm) const { return fast ? q0 + (gm >= next ? 1 : 0) : gm / period; }
+    __device__ __forceinline__ int inner(int gm) const { return gm - batch(gm) * period; }
+};
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
                                               int wn, int kh, int li) {
+    const bool has_div = g.div != 0.f, has_gate = g.gate != nullptr, has_resid = g.resid != nullptr, qkv = g.epi != GEPI_PLAIN;
+#ifdef ER_GEMM_PROBE_NO_EPILOGUE      // scripts/probes/gemm_hh_probe.hip: what the k-loop costs without the stores
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + wn * 32 * TN + j * 32 + li;
+        if (gn >= g.N) continue;
+        const float bias = g.bias ? g.bias[gn] : 0.f;
+        // GEPI_QKV: column -> (q | k | v, head, dim)
+        int which = 0, qc = 0;
+        long long kv_col = 0;
+        if (qkv) {
+            which = gn / g.hidden;
+            qc = gn - which * g.hidden;
+            const int h = qc / g.head_dim, d = qc - h * g.head_dim;
+            kv_col = (long long)h * g.l_cap * g.head_dim + d;
+        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i) {
+            const int row0 = m0 + wm * 32 * TM + i * 32;
+            const RowBatch gb(row0, has_gate ? g.gate_rows : 0), rb(row0, (has_resid && g.resid_mod > 0) ? g.resid_mod : 0),
+                           sb(row0, qkv ? g.S : 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int gn = n0 + wn * 32 * TN + j * 32 + li;
-                if (gm >= g.M || gn >= g.N) continue;
+                const int gm = row0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (gm >= g.M) continue;
                 float v = acc[i][j][r];
-                if (g.div != 0.f) v = v / g.div;
-                if (g.bias) v += g.bias[gn];
+                if (has_div) v = v / g.div;
+                v += bias;
                 if (g.relu) v = fmaxf(v, 0.f);
-                if (g.gate) v *= g.gate[(long long)(gm / g.gate_rows) * g.gate_bstride + gn];
-                if (g.resid) v += g.resid[(long long)(g.resid_mod > 0 ? gm % g.resid_mod : gm) * g.ldr + gn];
-                if (g.epi == GEPI_PLAIN) {
+                if (has_gate) v *= g.gate[(long long)gb.batch(gm) * g.gate_bstride + gn];
+                if (has_resid) v += g.resid[(long long)(g.resid_mod > 0 ? rb.inner(gm) : gm) * g.ldr + gn];
+                if (!qkv) {
                     C[(long long)gm * g.ldc + gn] = v;
+                    if (g.c16) g.c16[(long long)gm * g.ldc16 + gn] = (_Float16)v;
+                } else if (which == 0) {
+                    g.q[(long long)gm * g.hidden + qc] = v;
                 } else {
-                    const int which = gn / g.hidden, c = gn - which * g.hidden;
-                    if (which == 0) {
-                        g.q[(long long)gm * g.hidden + c] = v;
-                    } else {
-                        const int b = gm / g.S, s = gm - b * g.S;
-                        const int h = c / g.head_dim, d = c - h * g.head_dim;
-                        float* cache = (which == 1) ? g.kcache : g.vcache;
-                        cache[(long long)b * g.kv_bstride + ((long long)h * g.l_cap + s) * g.head_dim + d] = v;
-                    }
+                    float* cache = (which == 1) ? g.kcache : g.vcache;
+                    cache[(long long)sb.batch(gm) * g.kv_bstride + kv_col + (long long)sb.inner(gm) * g.head_dim] = v;
                 }
             }
+        }
+    }
 }
 
 template <int TM, int TN>
@@ -406,6 +444,218 @@ __global__ __launch_bounds__(ER_WG) void gemm_f16s_mfma_kernel(GemmArgs g) {
     gemm_epilogue<TM, TN>(g, g.C, acc, m0, n0, wm, wn, kh, li);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp16 x fp16 variant with BOTH operands brought in by LDS-DMA (global_load_lds_dwordx4): for the compute-bound front-end GEMMs
+// whose activations already exist in fp16 (the producing kernel - adaLN-modulated LayerNorm, attention, GEGLU, a GEMM epilogue -
+// writes an fp16 copy of what it hands to the next Linear, rounding exactly where gemm_f16_mfma_kernel rounds on its way in, so
+// the results are bit-identical to that kernel's).  Round 2's kernel staged both operands through registers (fp32 A converted in
+// the loop, one LDS stage, two barriers per 32-deep k-tile): 19-25 % MFMA-busy with a third of the LDS cycles lost to bank conflicts
+// (profiles/r02_pmc_sq_prefill_fp16.json).  Here:
+//   * k-tile 64, two LDS stages, ONE barrier per k-tile; no staging registers, no conversion, no ds_write at all;
+//   * the LDS image of a tile row is its 128 bytes (8 chunks of 16 B) with chunk c stored at slot c ^ ((row >> 1) & 7).  LDS-DMA
+//     writes lane-linearly (wave-uniform base + 16 B x lane), so the permutation is applied to the per-lane GLOBAL address (the 8
+//     lanes of a row still read one 128-byte line); the fragment reads (lane l: row l & 31, chunk 2 ks + (l >> 5)) then hit 16
+//     different 16-byte bank groups per 16-lane group: conflict-free ds_read_b128;
+//   * XCD-aware tile order: the 1-D grid is remapped so that each XCD's L2 sees a contiguous run of tiles (neighbouring tiles
+//     share their A row panel) instead of every eighth one (profiles/r02_pmc_hbm_summary.json: 6.4x operand re-fetch).
+// Requires K % 64 == 0, lda / ldb multiples of 8 halves, 16-byte aligned operands.  Rows beyond M / N are clamped on load and
+// dropped by the epilogue.
+constexpr int XBK = 64;
+typedef __attribute__((address_space(1))) const void* er_gptr;
+typedef __attribute__((address_space(3))) void* er_lptr;
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+// Epilogue of the LDS-DMA kernel.  The MFMA accumulator holds a COLUMN per lane (4 consecutive rows per register quad), so storing
+// it directly costs 64 four-byte stores per lane: measured store-issue-bound - 58 of the 68 us of a 4096 x 8192 x 64 product, i.e.
+// 134 MB at 2.3 TB/s, and ~25 us of fixed cost per workgroup at every K (profiles/r03_gemm_hh_probe.log).  Here every wave
+// transposes its (32 TM) x (32 TN) block through its own slice of the (now idle) stage buffers and finishes ROW-wise: 16 bytes per
+// lane, 16 lanes per 256-byte row segment, bias / gate / residual as float4 loads.
+//   HEPI_PLAIN: C = f(acc) (+ optional fp16 copy c16).
+//   HEPI_GEGLU: the B rows were permuted (gemm_hh_geglu_row) so that the wave's columns [0,32) are the GEGLU value part and
+//               [32,64) the gate part of the SAME 32 outputs: out16[m][j] = fp16((x + bx) * gelu_erf(gt + bg))
+//               (core/transformer/dit.py FeedForward / point.py:68-71), the [M][2F] pre-activation never reaches HBM.
+enum { HEPI_PLAIN = 0, HEPI_GEGLU = 1 };
+
+// row of the ORIGINAL [2F][K] GEGLU weight that sits at row p of the permuted copy (tile = 128 columns = 4 blocks of 32:
+// {value j0..j0+31, gate j0..j0+31, value j0+32.., gate j0+32..}); host and device agree through this one function
+__host__ __device__ inline int gemm_hh_geglu_row(int p, int F) {
+    const int tile = p >> 7, local = p & 127, wn = local >> 6, blk = (local >> 5) & 1, l = local & 31;
+    const int j = tile * 64 + wn * 32 + l;
+    return blk == 0 ? j : F + j;
+}
+
+template <int TM, int TN, int HEPI>
+__device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+    constexpr int WR = 32 * TM, WC = 32 * TN;
+    static_assert(HEPI == HEPI_PLAIN || TN == 2, "GEGLU pairs the wave's two 32-column blocks");
+    const int kh = lane >> 5, li = lane & 31;
+#ifdef ER_GEMM_PROBE_NO_EPILOGUE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sw[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh) * WC + 32 * j + li] = acc[i][j][r];
+    // (same wave writes and reads: the LDS queue is in order, no barrier)
+    if constexpr (HEPI == HEPI_PLAIN) {
+        constexpr int LPR = WC / 4, RPP = 64 / LPR;              // lanes per row, rows per pass
+        const int c4 = lane % LPR, rr0 = lane / LPR;
+        const int gn = nw + 4 * c4;
+        if (gn >= g.N) return;
+        const bool vec = gn + 3 < g.N && !(g.ldc & 3) && (!g.resid || !(g.ldr & 3)) && !(g.gate_bstride & 3) && (!g.c16 || !(g.ldc16 & 3));
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+            bias.x = g.bias[gn];
+            if (gn + 1 < g.N) bias.y = g.bias[gn + 1];
+            if (gn + 2 < g.N) bias.z = g.bias[gn + 2];
+            if (gn + 3 < g.N) bias.w = g.bias[gn + 3];
+        }
+        const RowBatch gb(mw, g.gate ? g.gate_rows : 0, WR), rb(mw, (g.resid && g.resid_mod > 0) ? g.resid_mod : 0, WR);
+#pragma unroll 4
+        for (int t = 0; t < WR / RPP; ++t) {
+            const int rr = rr0 + RPP * t, gm = mw + rr;
+            if (gm >= g.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c4);
+            if (g.div != 0.f) { v.x = v.x / g.div; v.y = v.y / g.div; v.z = v.z / g.div; v.w = v.w / g.div; }
+            v += bias;
+            if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const long long rrow = g.resid ? (long long)(g.resid_mod > 0 ? rb.inner(gm) : gm) * g.ldr + gn : 0;
+            const long long grow = g.gate ? (long long)gb.batch(gm) * g.gate_bstride + gn : 0;
+            if (vec) {
+                if (g.gate) v *= *reinterpret_cast<const f32x4*>(g.gate + grow);
+                if (g.resid) v += *reinterpret_cast<const f32x4*>(g.resid + rrow);
+                *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;
+                if (g.c16) *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * g.ldc16 + gn) = (h16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (gn + u >= g.N) break;
+                    float w = e[u];
+                    if (g.gate) w *= g.gate[grow + u];
+                    if (g.resid) w += g.resid[rrow + u];
+                    g.C[(long long)gm * g.ldc + gn + u] = w;
+                    if (g.c16) g.c16[(long long)gm * g.ldc16 + gn + u] = (_Float16)w;
+                }
+            }
+        }
+    } else {
+        // GEGLU: lane -> (row, 4 outputs): value part at columns 4 c .. +3, gate part at 32 + 4 c .. +3 of the wave's block
+        constexpr int LPR = 8, RPP = 8;
+        const int c = lane % LPR, rr0 = lane / LPR;
+        const int F = g.N >> 1;                                   // outputs per row
+        const int jo = (nw >> 1) + 4 * c;                         // output column: permuted column nw + l <-> output nw / 2 + l
+        const f32x4 bx = *reinterpret_cast<const f32x4*>(g.bias + nw + 4 * c), bg = *reinterpret_cast<const f32x4*>(g.bias + nw + 32 + 4 * c);
+#pragma unroll 4
+        for (int t = 0; t < WR / RPP; ++t) {
+            const int rr = rr0 + RPP * t, gm = mw + rr;
+            if (gm >= g.M) continue;
+            f32x4 x = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c);
+            f32x4 gt = *reinterpret_cast<const f32x4*>(sw + rr * WC + 32 + 4 * c);
+            x += bx;
+            gt += bg;
+            const float o0 = x.x * (gt.x * 0.5f * (1.0f + erff(gt.x * 0.70710678118654752440f)));
+            const float o1 = x.y * (gt.y * 0.5f * (1.0f + erff(gt.y * 0.70710678118654752440f)));
+            const float o2 = x.z * (gt.z * 0.5f * (1.0f + erff(gt.z * 0.70710678118654752440f)));
+            const float o3 = x.w * (gt.w * 0.5f * (1.0f + erff(gt.w * 0.70710678118654752440f)));
+            *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * F + jo) = (h16x4){(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
+        }
+    }
+}
+
+template <int TM, int TN, int HEPI = HEPI_PLAIN>
+__global__ __launch_bounds__(ER_WG) void gemm_hh_mfma_kernel(GemmArgs g, int ntx) {
+    constexpr int GBM = 64 * TM, GBN = 64 * TN, STAGE = (GBM + GBN) * XBK;     // halves per stage: A rows, then B rows
+    constexpr int NAI = GBM / 32, NBI = GBN / 32;                                // 8-row LDS-DMA pieces per wave and operand
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * STAGE];             // the ONLY LDS object (a second one makes hipcc drain vmcnt per k-step)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    // XCD-aware tile order (bijective for any grid size)
+    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + within;
+    const int ty = lin / ntx, tx = lin - ty * ntx;
+    const int m0 = ty * GBM, n0 = tx * GBN;
+    const _Float16* A = reinterpret_cast<const _Float16*>(g.A);
+    const _Float16* B = reinterpret_cast<const _Float16*>(g.B);
+    const int nk = g.K / XBK;
+
+    // per-lane source pointers of this wave's LDS-DMA pieces: piece i covers tile rows 8i .. 8i+7, lane -> (row 8i + lane/8, slot lane%8)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const _Float16* pa[NAI];
+    const _Float16* pb[NBI];
+#pragma unroll
+    for (int j = 0; j < NAI; ++j) {
+        const int r = 8 * (wid * NAI + j) + lrow;
+        pa[j] = A + (long long)min(m0 + r, g.M - 1) * g.lda + ((lslot ^ ((r >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < NBI; ++j) {
+        const int r = 8 * (wid * NBI + j) + lrow;
+        pb[j] = B + (long long)min(n0 + r, g.N - 1) * g.ldb + ((lslot ^ ((r >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int kt, int s) {
+        _Float16* as = lds + s * STAGE;
+        _Float16* bs = as + GBM * XBK;
+#pragma unroll
+        for (int j = 0; j < NAI; ++j)
+            __builtin_amdgcn_global_load_lds((er_gptr)(pa[j] + kt * XBK), (er_lptr)(as + 8 * (wid * NAI + j) * XBK), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NBI; ++j)
+            __builtin_amdgcn_global_load_lds((er_gptr)(pb[j] + kt * XBK), (er_lptr)(bs + 8 * (wid * NBI + j) * XBK), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kh = lane >> 5, li = lane & 31, swz = (li >> 1) & 7;
+    if (nk > 0) issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);      // lands while this tile is multiplied
+        const _Float16* as = lds + cur * STAGE + (wm * 32 * TM + li) * XBK;
+        const _Float16* bs = lds + cur * STAGE + GBM * XBK + (wn * 32 * TN + li) * XBK;
+#pragma unroll
+        for (int ks = 0; ks < XBK / 16; ++ks) {
+            const int co = ((2 * ks + kh) ^ swz) << 3;
+            h16x8 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const h16x8*>(as + 32 * i * XBK + co);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const h16x8*>(bs + 32 * j * XBK + co);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile have landed ...
+        __syncthreads();                                    // ... and everybody's; everybody is done reading `cur`
+    }
+    // every wave is past the last barrier: the stage buffers are free.  Wave w's (32 TM) x (32 TN) floats fit its quarter of them
+    static_assert(4 * 32 * TM * 32 * TN * 4 <= 2 * STAGE * 2, "epilogue staging fits the stage buffers");
+    float* sw = reinterpret_cast<float*>(lds) + wid * (32 * TM * 32 * TN);
+    gemm_hh_epilogue<TM, TN, HEPI>(g, sw, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+}
+
+// fp32 -> fp16 copy of a row-major matrix (the A operand of gemm_hh_mfma_kernel when no producer wrote one)
+__global__ __launch_bounds__(ER_WG) void cvt_rows_f16_kernel(const float* x, _Float16* y, long long rows, int cols, int ldx, int ldy) {
+    const long long total = rows * cols;
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
+        const long long r = i / cols;
+        const int c = (int)(i - r * cols);
+        y[r * ldy + c] = (_Float16)x[r * ldx + c];
+    }
+}
+
 inline GemmArgs gemm_args_default() {
     GemmArgs g{};
     g.Z2 = 1;
@@ -444,6 +694,40 @@ inline int gemm_pick_tile(int M, int N, int batch) {
 
 inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT only, K % 32 == 0, B = fp16 weights
     ER_GEMM_DISPATCH(ER_K_F16, g, 1, st);
+    return hipGetLastError();
+}
+
+// A = fp16 [M][lda], B = fp16 weights [N][ldb] (both through g.A / g.B), K % 64 == 0
+inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st) {
+    if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7)) return hipErrorInvalidValue;
+    const int tile = gemm_pick_tile(g.M, g.N, 1);
+    const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
+    const int ntx = (g.N + bn - 1) / bn, nty = (g.M + bm - 1) / bm;
+    const dim3 grid(ntx * nty);
+    if (tile == 1) hipLaunchKernelGGL((gemm_hh_mfma_kernel<2, 2>), grid, dim3(ER_WG), 0, st, g, ntx);
+    else if (tile == 2) hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 2>), grid, dim3(ER_WG), 0, st, g, ntx);
+    else hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 1>), grid, dim3(ER_WG), 0, st, g, ntx);
+    return hipGetLastError();
+}
+
+// builds the permuted GEGLU operands: wp[p][:] = w[gemm_hh_geglu_row(p, F)][:], bp[p] = b[gemm_hh_geglu_row(p, F)]   (p < 2F)
+__global__ __launch_bounds__(ER_WG) void geglu_permute_kernel(const _Float16* w, const float* b, _Float16* wp, float* bp, int F, int K) {
+    const int p = blockIdx.x, src = gemm_hh_geglu_row(p, F);
+    for (int k = threadIdx.x * 8; k < K; k += ER_WG * 8)
+        *reinterpret_cast<h16x8*>(wp + (long long)p * K + k) = *reinterpret_cast<const h16x8*>(w + (long long)src * K + k);
+    if (threadIdx.x == 0) bp[p] = b[src];
+}
+
+// out16[M][F] = fp16(GEGLU(A . Wp^T + bp)): Wp / bp = the [2F][K] weight / [2F] bias permuted by gemm_hh_geglu_row (g.B, g.bias),
+// g.N = 2F (a multiple of 128), g.c16 = out16; no fp32 output
+inline hipError_t launch_gemm_hh_geglu(const GemmArgs& g, hipStream_t st) {
+    if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7) || (g.N & 127) || !g.c16 || !g.bias) return hipErrorInvalidValue;
+    const int ntx = g.N / 128;
+    if ((long long)((g.M + 127) / 128) * ntx >= 768) {
+        hipLaunchKernelGGL((gemm_hh_mfma_kernel<2, 2, HEPI_GEGLU>), dim3(ntx * ((g.M + 127) / 128)), dim3(ER_WG), 0, st, g, ntx);
+    } else {
+        hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 2, HEPI_GEGLU>), dim3(ntx * ((g.M + 63) / 64)), dim3(ER_WG), 0, st, g, ntx);
+    }
     return hipGetLastError();
 }
 

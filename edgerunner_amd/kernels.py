@@ -77,6 +77,19 @@ def gemm_f16(a, w_half, bias=None, resid=None, relu=False):
     return c
 
 
+def gemm_hh(a, w_half, bias=None, resid=None, relu=False, return_half=False):
+    """The same product through the LDS-DMA kernel (both operands fp16 in HBM; a is rounded to an fp16 copy first); K % 64 == 0.
+    return_half: also return the epilogue's fp16 copy of the result."""
+    lib = native.load_library()
+    M, K = a.shape
+    N = w_half.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    c16 = torch.empty((M, N), dtype=torch.float16, device=a.device) if return_half else None
+    native.check(lib.er_k_gemm_hh(native.ptr(a), native.ptr(w_half), native.ptr(bias), native.ptr(resid), native.ptr(c), native.ptr(c16),
+                                  M, N, K, a.stride(0), w_half.stride(0), c.stride(0), int(relu), _st()), "er_k_gemm_hh")
+    return (c, c16) if return_half else c
+
+
 def gemm_f16s(a, w_half, bias=None, resid=None, relu=False):
     """C = relu?(fp16(A) . W^T + bias) (+resid) on the fp16-input MFMA path; a fp32 [M,K], w_half fp16 [N,K]."""
     lib = native.load_library()
@@ -113,8 +126,8 @@ def flash_attn_f32(q, k, v, heads, causal=False):
 
 
 def flash_attn_f16s(q, k, v, heads, causal=False):
-    """STAGED (round 3): the same attention for head_dim 96 on the fp16 matrix cores with hi/lo-split q and p; k / v must
-    hold fp16-representable values."""
+    """The same attention for head_dim 96 on the fp16 matrix cores with hi/lo-split q and p; k / v must hold
+    fp16-representable values (fast-mode prefix attention of batches)."""
     lib = native.load_library()
     B, N, HD = q.shape
     assert HD // heads == 96

@@ -274,6 +274,10 @@ int er_k_gemm_f16(const float* a_dev, const void* w_half_dev, const float* bias_
                   float* c_dev, int m, int n, int k, int lda, int ldb, int ldc, int relu, void* stream);
 /* Same shape with the fp32 activations split into fp16 hi + lo parts on their way to the matrix cores (fp32-grade operand,
  * two fp16 MFMAs per fragment): the fast-mode prefill Linears (fp16-stored weights x fp32 activations, fp32 accumulate). */
+/* the same product with BOTH operands in fp16 brought in by LDS-DMA (k % 64 == 0): a is rounded to an fp16 copy first (in the
+ * DiT path the producing kernel writes that copy); c16_out_dev (optional) receives the result rounded to fp16 [m][n] */
+int er_k_gemm_hh(const float* a_dev, const void* w_half_dev, const float* bias_dev, const float* resid_dev, float* c_dev,
+                 void* c16_out_dev, int m, int n, int k, int lda, int ldb, int ldc, int relu, void* stream);
 int er_k_gemm_f16s(const float* a, const void* w_half, const float* bias, const float* resid, float* c, int m, int n, int k,
                    int lda, int ldb, int ldc, int relu, void* stream);
 /* softmax(q k^T / 8) v, head_dim 64, non-causal, fp16 operands / fp32 accumulate; q,o [B,N,H*64], k,v [B,M,H*64] fp32 */

@@ -1,0 +1,57 @@
+// Throughput of the library's LDS-DMA fp16 GEMM (k_gemm.h, gemm_hh_mfma_kernel) and of the register-staged fp16 kernel it replaces,
+// on the DiT shapes and on 4096^3 (the shape the programming guide's ladder quotes: 128^2 tile + 16-byte LDS-DMA = 874 TF).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ../../edgerunner_amd/csrc -o gemm_hh_probe gemm_hh_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "k_gemm.h"
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+using namespace er;
+
+int main() {
+    const int shapes[][3] = {{4096, 4096, 4096}, {4096, 3072, 1024}, {4096, 8192, 1024}, {4096, 8192, 64}, {4096, 8192, 256}, {4096, 1024, 4096}, {4096, 1024, 1024}, {8192, 8192, 8192}};
+    hipStream_t st;
+    CHECK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (auto& s : shapes) {
+        const int M = s[0], N = s[1], K = s[2];
+        _Float16 *A, *B;
+        float *Af, *C;
+        CHECK(hipMalloc(&A, (size_t)M * K * 2));
+        CHECK(hipMalloc(&B, (size_t)N * K * 2));
+        CHECK(hipMalloc(&Af, (size_t)M * K * 4));
+        CHECK(hipMalloc(&C, (size_t)M * N * 4));
+        std::vector<float> h((size_t)M * K);
+        unsigned x = 7u;
+        for (auto& v : h) { x = x * 1664525u + 1013904223u; v = ((float)(x >> 8) / 8388608.0f - 1.0f); }
+        CHECK(hipMemcpy(Af, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(4096), dim3(ER_WG), 0, st, Af, A, (long long)M, K, K, K);
+        std::vector<_Float16> hb((size_t)N * K);
+        for (auto& v : hb) { x = x * 1664525u + 1013904223u; v = (_Float16)(((float)(x >> 8) / 8388608.0f - 1.0f) * 0.05f); }
+        CHECK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        GemmArgs g = gemm_args_default();
+        g.B = reinterpret_cast<const float*>(B); g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
+        const double flop = 2.0 * M * N * K;
+        for (int variant = 0; variant < 2; ++variant) {
+            g.A = variant == 0 ? reinterpret_cast<const float*>(A) : Af;
+            auto run = [&]() { return variant == 0 ? launch_gemm_hh(g, st) : launch_gemm_f16(g, st); };
+            CHECK(run());
+            CHECK(hipStreamSynchronize(st));
+            const int reps = 10;
+            CHECK(hipEventRecord(e0, st));
+            for (int r = 0; r < reps; ++r) CHECK(run());
+            CHECK(hipEventRecord(e1, st));
+            CHECK(hipStreamSynchronize(st));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%5d x %5d x %5d  %-28s %8.1f us  %7.1f TFLOP/s  (tile rule %d)\n", M, N, K,
+                   variant == 0 ? "LDS-DMA fp16 x fp16" : "register-staged, fp32 A", ms * 1e3 / reps, flop / (ms * 1e-3 / reps) / 1e12,
+                   gemm_pick_tile(M, N, 1));
+        }
+        hipFree(A); hipFree(B); hipFree(Af); hipFree(C);
+    }
+    return 0;
+}

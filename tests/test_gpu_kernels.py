@@ -181,10 +181,9 @@ def test_attn_decode_fp16_cache(D, lens, steps, variant):
 
 
 @pytest.mark.parametrize("B,H,N,M,causal", [(2, 16, 2050, 2050, True), (1, 3, 100, 333, False), (1, 2, 33, 33, True)])
-def test_flash_attn_f16s_staged(B, H, N, M, causal):
-    """Fast-mode prefill attention on the fp16 matrix cores with hi/lo-split q and p (staged for round 3: selected by
-    ER_PREFILL_ATTN_F16S=1 only, not timed yet): fp16-valued k / v, fp32 q; must agree with float64 to fp32 round-off like the
-    fp32 kernel (3 passed on the GPU at the end of round 2)."""
+def test_flash_attn_f16s(B, H, N, M, causal):
+    """Fast-mode prefill attention on the fp16 matrix cores with hi/lo-split q and p (the default for batches of >= 2 prefixes):
+    fp16-valued k / v, fp32 q; must agree with float64 to fp32 round-off like the fp32 kernel."""
     from edgerunner_amd import kernels as K
     D = 96
     q = rnd(B, N, H * D, seed=80)
@@ -302,6 +301,30 @@ def test_gemm_f16_input_mfma(M, N, K):
     eye = torch.eye(256, device=DEV)
     wq = ((torch.arange(256 * 256, device=DEV, dtype=torch.float32).view(256, 256) % 509) / 8.0).half()
     assert torch.equal(K_.gemm_f16(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (4096, 3072, 1024), (4096, 1024, 4096), (4096, 64, 1024), (514, 1024, 1024),
+                                   (77, 200, 640), (300, 8192, 1024), (129, 65, 128)])
+def test_gemm_hh_lds_dma(M, N, K):
+    """fp16 x fp16 GEMM with both operands brought in by LDS-DMA into an XOR-swizzled image (DiT Linears in fp16 mode): must be
+    BIT-IDENTICAL to the register-staged fp16 kernel (same fp16-rounded operands, same k order per MFMA, same epilogue), for all
+    three tile shapes, ragged edges and the XCD-aware tile order; the fp16 copy of the output is the rounded fp32 output."""
+    from edgerunner_amd import kernels as K_
+    a, w = rnd(M, K, seed=84), rnd(N, K, seed=85, scale=0.05)
+    bias, resid = rnd(N, seed=86), rnd(M, N, seed=87)
+    wh = w.half()
+    ref = a.half().double() @ wh.double().T + bias.double()
+    c, c16 = K_.gemm_hh(a, wh, bias, resid, return_half=True)
+    close(c, ref + resid.double(), 1e-5 + 2e-7 * K, 1e-5, "LDS-DMA fp16 gemm")
+    assert torch.equal(c16, c.half()), "fp16 copy of the output"
+    if K % 32 == 0:
+        assert torch.equal(c, K_.gemm_f16(a, wh, bias, resid)), "must equal the register-staged fp16 kernel bit for bit"
+    c2 = K_.gemm_hh(a, wh, bias, None, relu=True)
+    close(c2, torch.relu(ref), 1e-5 + 2e-7 * K, 1e-5, "LDS-DMA fp16 gemm relu")
+    if M >= 256 and N >= 256 and K >= 256:      # asymmetric operand: catches a transposed fragment map / a wrong swizzle
+        eye = torch.eye(256, device=DEV)
+        wq = ((torch.arange(256 * 256, device=DEV, dtype=torch.float32).view(256, 256) % 509) / 8.0).half()
+        assert torch.equal(K_.gemm_hh(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (2050, 4608, 1536), (2050, 1536, 6144), (514, 3072, 1024), (77, 200, 608)])

@@ -418,8 +418,7 @@ def test_fast_mode_vs_storage_rounding_emulation(gold_small):
     assert err < LOGIT_TOL
 
 
-@pytest.mark.skipif(os.environ.get("ER_TEST_STAGED") != "1", reason="staged for round 3: ER_PREFILL_ATTN_F16S is unit-tested but has not been through this end-to-end check on a GPU yet")
-def test_fast_mode_with_staged_split_fp16_prefix_attention(monkeypatch):
+def test_fast_mode_with_split_fp16_prefix_attention(monkeypatch):
     """ER_PREFILL_ATTN_F16S=1 (prefix attention on the fp16 matrix cores, hi/lo-split q and p): the fast-mode model must stay
     the model the default fp32-matrix-core attention computes - same greedy ids, prefill logits to fp32 round-off."""
     base = make_lmm(precision="fp16")
