@@ -1578,6 +1578,34 @@ extern "C" int er_k_flash_attn_f16(const float* q, const float* k, const float* 
     return ER_OK;
 }
 
+// the LDS-DMA variant (q / k / v in fp16, V transposed per head): converts and transposes the fp32 inputs first - in the DiT
+// path the qkv GEMM epilogue and transpose_v_f16_kernel produce these operands - and returns the fp16 output widened to fp32
+extern "C" int er_k_flash_attn_hh(const float* q, const float* k, const float* v, float* o, int B, int H, int N, int M, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int C = H * FA_D, Mp = (M + 63) / 64 * 64;
+    _Float16 *q16 = nullptr, *k16 = nullptr, *v16 = nullptr, *vt = nullptr, *o16 = nullptr;
+    HIPCHK(hipMalloc(&q16, (size_t)B * N * C * 2));
+    HIPCHK(hipMalloc(&k16, (size_t)B * M * C * 2));
+    HIPCHK(hipMalloc(&v16, (size_t)B * M * C * 2));
+    HIPCHK(hipMalloc(&vt, (size_t)B * H * 64 * Mp * 2));
+    HIPCHK(hipMalloc(&o16, (size_t)B * N * C * 2));
+    hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)B * N * C)), dim3(ER_WG), 0, st, q, q16, (long long)B * N, C, C, C);
+    hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)B * M * C)), dim3(ER_WG), 0, st, k, k16, (long long)B * M, C, C, C);
+    hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)B * M * C)), dim3(ER_WG), 0, st, v, v16, (long long)B * M, C, C, C);
+    hipLaunchKernelGGL(transpose_v_f16_kernel, dim3(Mp / 64, H, B), dim3(ER_WG), 0, st, v16, vt, M, Mp, C, (long long)M * C);
+    FlashHArgs a{};
+    a.Q = q16; a.K = k16; a.Vt = vt; a.O16 = o16; a.N = N; a.M = M; a.ldq = a.ldk = a.ldo = C; a.ldvt = Mp;
+    a.qs_b = a.os_b = (long long)N * C; a.ks_b = (long long)M * C; a.vts_h = 64LL * Mp; a.vts_b = (long long)H * 64 * Mp;
+    a.head_stride = FA_D; a.scale = 1.0f / sqrtf((float)FA_D);
+    hipError_t e = launch_flash_attn_hh(a, H, B, st);
+    hipLaunchKernelGGL(cvt_f16_rows_f32_kernel, dim3(ew_grid((long long)B * N * C)), dim3(ER_WG), 0, st, o16, o, (long long)B * N * C);
+    hipError_t e2 = hipStreamSynchronize(st);
+    for (void* p : {(void*)q16, (void*)k16, (void*)v16, (void*)vt, (void*)o16}) hipFree(p);
+    HIPRET(e);
+    HIPRET(e2);
+    return ER_OK;
+}
+
 extern "C" int er_k_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int N, int M, int D,
                                    int causal, void* stream) {
     // q/o: [B, N, H*D], k/v: [B, M, H*D] fp32, heads side by side in a row; causal: key j visible to query i iff j <= i + (M - N)

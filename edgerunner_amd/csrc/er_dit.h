@@ -43,6 +43,9 @@ struct er_dit_ctx {
     Buf x, qkv, att, q2, kv2, u, g, sc, tin, temb0, temb1, temb, tsil, tada, gate, t_dev, xin, pred, czero, ctmp;
     // fp16 mode: fp16 copies of the activations that feed a Linear, written by their producers (k_gemm.h, gemm_hh_mfma_kernel)
     Buf x16, att16, g16;
+    // ... and q / k / v in fp16 with V transposed, for the LDS-DMA attention (k_flash_attn.h, flash_attn_hh_kernel)
+    Buf qkv16, vt16, q2_16, k2_16, v2tmp16, v2t16;
+    int kv2_mp = 0;                        // padded key count of the cross-attention V^T rows
     bool geglu_perm_valid = false;
 };
 
@@ -133,7 +136,8 @@ extern "C" int er_dit_destroy(er_dit_ctx* c) {
     for (Buf* b : {&c->cpx, &c->ccol, &c->cpatch, &c->cx, &c->ch, &c->cq, &c->ck, &c->cv, &c->catt, &c->cf})
         if (b->p) hipFree(b->p);
     for (Buf* b : {&c->x, &c->qkv, &c->att, &c->q2, &c->kv2, &c->u, &c->g, &c->sc, &c->tin, &c->temb0, &c->temb1, &c->temb,
-                   &c->tsil, &c->tada, &c->gate, &c->t_dev, &c->xin, &c->pred, &c->czero, &c->ctmp, &c->x16, &c->att16, &c->g16})
+                   &c->tsil, &c->tada, &c->gate, &c->t_dev, &c->xin, &c->pred, &c->czero, &c->ctmp, &c->x16, &c->att16, &c->g16,
+                   &c->qkv16, &c->vt16, &c->q2_16, &c->k2_16, &c->v2tmp16, &c->v2t16})
         if (b->p) hipFree(b->p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -344,6 +348,24 @@ static int dit_cross_kv(er_dit_ctx* c, const float* cond, int B, int M, hipStrea
         HIPRET(dlin(c, cond, C, L.k2_w, L.k2_b, k2, C, B * M, C, C, nullptr, 0, nullptr, 1, st));
         HIPRET(dlin(c, cond, C, L.v2_w, L.v2_b, v2, C, B * M, C, C, nullptr, 0, nullptr, 1, st));
     }
+    if (c->fast && C / c->cfg.num_heads == FA_D) {      // fp16 K and V^T (zero-padded to a multiple of 64 keys) for flash_attn_hh_kernel
+        const int H = c->cfg.num_heads, Mp = (M + 63) / 64 * 64;
+        c->kv2_mp = Mp;
+        ERCHK(ensure(c->k2_16, (size_t)nl * B * M * C / 2 + 8));
+        ERCHK(ensure(c->v2tmp16, (size_t)B * M * C / 2 + 8));
+        ERCHK(ensure(c->v2t16, (size_t)nl * B * H * 64 * Mp / 2 + 8));
+        for (int l = 0; l < nl; ++l) {
+            const float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
+            const float* v2 = k2 + (size_t)B * M * C;
+            _Float16* k16 = reinterpret_cast<_Float16*>(c->k2_16.p) + (size_t)l * B * M * C;
+            _Float16* vtmp = reinterpret_cast<_Float16*>(c->v2tmp16.p);
+            _Float16* vt = reinterpret_cast<_Float16*>(c->v2t16.p) + (size_t)l * B * H * 64 * Mp;
+            hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)B * M * C)), dim3(ER_WG), 0, st, k2, k16, (long long)B * M, C, C, C);
+            hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)B * M * C)), dim3(ER_WG), 0, st, v2, vtmp, (long long)B * M, C, C, C);
+            hipLaunchKernelGGL(transpose_v_f16_kernel, dim3(Mp / 64, H, B), dim3(ER_WG), 0, st, vtmp, vt, M, Mp, C, (long long)M * C);
+            HIPRET(hipGetLastError());
+        }
+    }
     return 0;
 }
 
@@ -376,6 +398,15 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     _Float16* att16 = hh ? reinterpret_cast<_Float16*>(c->att16.p) : nullptr;
     _Float16* g16 = hh ? reinterpret_cast<_Float16*>(c->g16.p) : nullptr;
     if (hh) ERCHK(dit_build_geglu_perm(c, st));
+    if (hh) {
+        ERCHK(ensure(c->qkv16, (size_t)R * 3 * C / 2 + 8));
+        ERCHK(ensure(c->vt16, (size_t)R * C / 2 + 8));
+        ERCHK(ensure(c->q2_16, (size_t)R * C / 2 + 8));
+    }
+    _Float16* qkv16 = hh ? reinterpret_cast<_Float16*>(c->qkv16.p) : nullptr;
+    _Float16* vt16 = hh ? reinterpret_cast<_Float16*>(c->vt16.p) : nullptr;
+    _Float16* q2_16 = hh ? reinterpret_cast<_Float16*>(c->q2_16.p) : nullptr;
+    if (hh && (N % 64 != 0 || c->kv2_mp != (M + 63) / 64 * 64)) return fail(ER_ERR_INVALID, "dit: fp16 attention operands are not prepared (latent_size %% 64, cross K/V)");
     ERCHK(dit_time_embed(c, B, st));
     float* x = c->x.p;
     // x = proj_in(x) + pos_embed                                                  dit.py:177-180
@@ -387,8 +418,18 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         // x = norm1(x) * (1 + scale_msa) + shift_msa   (chunks 0 = shift, 1 = scale, 2 = gate)     dit.py:129-132
         HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st, x16));
         // x = x + gate_msa * attn1(x)                                               dit.py:133
-        if (hh) HIPRET(dlin16(c, x16, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, nullptr, st));
-        else HIPRET(dlin(c, x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, st));
+        if (hh) {     // q, k, v leave the GEMM in fp16 only; V is transposed per head; K and V^T tiles then reach LDS by DMA
+            HIPRET(dlin16(c, x16, C, L.qkv_w, L.qkv_b, nullptr, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, qkv16, st));
+            hipLaunchKernelGGL(transpose_v_f16_kernel, dim3(N / 64, H, B), dim3(ER_WG), 0, st, qkv16 + 2 * C, vt16, N, N, 3 * C, (long long)N * 3 * C);
+            HIPRET(hipGetLastError());
+            FlashHArgs fh{};
+            fh.Q = qkv16; fh.K = qkv16 + C; fh.Vt = vt16; fh.O16 = att16; fh.N = N; fh.M = N;
+            fh.ldq = fh.ldk = 3 * C; fh.ldvt = N; fh.ldo = C;
+            fh.qs_b = fh.ks_b = (long long)N * 3 * C; fh.vts_h = 64LL * N; fh.vts_b = (long long)H * 64 * N; fh.os_b = (long long)N * C;
+            fh.head_stride = D; fh.scale = 1.0f / sqrtf((float)D);
+            HIPRET(launch_flash_attn_hh(fh, H, B, st));
+        } else {
+        HIPRET(dlin(c, x, C, L.qkv_w, L.qkv_b, c->qkv.p, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, st));
         if (flash) {
             FlashArgs fa{};
             fa.Q = c->qkv.p; fa.K = c->qkv.p + C; fa.V = c->qkv.p + 2 * C; fa.O = c->att.p; fa.N = N; fa.M = N;
@@ -404,17 +445,27 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
                                      c->sc.p, H, D, N, N, false, st));
             }
         }
+        }
         hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 2);
         HIPRET(hipGetLastError());
         // (the fp16 copy of the new x is the A operand of the cross-attention query projection)
         if (hh) HIPRET(dlin16(c, att16, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, x16, st));
         else HIPRET(dlin(c, c->att.p, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, st));
         // x = x + attn2(x, c)                                                       dit.py:135
-        if (hh) HIPRET(dlin16(c, x16, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, nullptr, st));
+        if (hh) HIPRET(dlin16(c, x16, C, L.q2_w, L.q2_b, nullptr, C, R, C, C, nullptr, 0, nullptr, 1, q2_16, st));
         else HIPRET(dlin(c, x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, st));
         const float* k2 = c->kv2.p + ((size_t)l * 2) * B * M * C;
         const float* v2 = k2 + (size_t)B * M * C;
-        if (flash) {
+        if (hh) {
+            const int Mp = c->kv2_mp;
+            FlashHArgs fh{};
+            fh.Q = q2_16; fh.K = reinterpret_cast<const _Float16*>(c->k2_16.p) + (size_t)l * B * M * C;
+            fh.Vt = reinterpret_cast<const _Float16*>(c->v2t16.p) + (size_t)l * B * H * 64 * Mp; fh.O16 = att16; fh.N = N; fh.M = M;
+            fh.ldq = fh.ldk = C; fh.ldvt = Mp; fh.ldo = C;
+            fh.qs_b = (long long)N * C; fh.ks_b = (long long)M * C; fh.vts_h = 64LL * Mp; fh.vts_b = (long long)H * 64 * Mp; fh.os_b = (long long)N * C;
+            fh.head_stride = D; fh.scale = 1.0f / sqrtf((float)D);
+            HIPRET(launch_flash_attn_hh(fh, H, B, st));
+        } else if (flash) {
             FlashArgs fa{};
             fa.Q = c->q2.p; fa.K = k2; fa.V = v2; fa.O = c->att.p; fa.N = N; fa.M = M;
             fa.ldq = fa.ldk = fa.ldv = fa.ldo = C;

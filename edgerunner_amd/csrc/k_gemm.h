@@ -504,7 +504,7 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
         const int c4 = lane % LPR, rr0 = lane / LPR;
         const int gn = nw + 4 * c4;
         if (gn >= g.N) return;
-        const bool vec = gn + 3 < g.N && !(g.ldc & 3) && (!g.resid || !(g.ldr & 3)) && !(g.gate_bstride & 3) && (!g.c16 || !(g.ldc16 & 3));
+        const bool vec = gn + 3 < g.N && (!g.C || !(g.ldc & 3)) && (!g.resid || !(g.ldr & 3)) && !(g.gate_bstride & 3) && (!g.c16 || !(g.ldc16 & 3));
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) {
             bias.x = g.bias[gn];
@@ -526,7 +526,7 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
             if (vec) {
                 if (g.gate) v *= *reinterpret_cast<const f32x4*>(g.gate + grow);
                 if (g.resid) v += *reinterpret_cast<const f32x4*>(g.resid + rrow);
-                *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;
+                if (g.C) *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;     // null: only the fp16 copy is wanted
                 if (g.c16) *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * g.ldc16 + gn) = (h16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
             } else {
                 const float e[4] = {v.x, v.y, v.z, v.w};
@@ -536,7 +536,7 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
                     float w = e[u];
                     if (g.gate) w *= g.gate[grow + u];
                     if (g.resid) w += g.resid[rrow + u];
-                    g.C[(long long)gm * g.ldc + gn + u] = w;
+                    if (g.C) g.C[(long long)gm * g.ldc + gn + u] = w;
                     if (g.c16) g.c16[(long long)gm * g.ldc16 + gn + u] = (_Float16)w;
                 }
             }
@@ -656,6 +656,11 @@ __global__ __launch_bounds__(ER_WG) void cvt_rows_f16_kernel(const float* x, _Fl
     }
 }
 
+__global__ __launch_bounds__(ER_WG) void cvt_f16_rows_f32_kernel(const _Float16* x, float* y, long long n) {
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < n; i += (long long)gridDim.x * ER_WG) y[i] = (float)x[i];
+}
+
+inline int gemm_pick_tile(int M, int N, int batch);
 inline GemmArgs gemm_args_default() {
     GemmArgs g{};
     g.Z2 = 1;
@@ -697,10 +702,20 @@ inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT o
     return hipGetLastError();
 }
 
+// tile choice of the LDS-DMA kernel (see gemm_pick_tile): placeholder rule, tuned by scripts/probes/gemm_hh_probe.hip
+// (profiles/r03_gemm_hh_probe.log): 128x128 wants two workgroups per CU (its 64 KB of stages allow no more); below that 64x128
+// at >= 1 per CU beats both 128x128 at < 2 per CU and 64x64 (4096 x 1024 x 4096: 51 vs 54 vs 62 us)
+inline int gemm_hh_pick_tile(int M, int N) {
+    auto wgs = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (wgs(128, 128) >= 512) return 1;
+    if (wgs(64, 128) >= 256) return 2;
+    return 3;
+}
+
 // A = fp16 [M][lda], B = fp16 weights [N][ldb] (both through g.A / g.B), K % 64 == 0
-inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st) {
+inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st, int force_tile = 0) {
     if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7)) return hipErrorInvalidValue;
-    const int tile = gemm_pick_tile(g.M, g.N, 1);
+    const int tile = force_tile ? force_tile : gemm_hh_pick_tile(g.M, g.N);
     const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
     const int ntx = (g.N + bn - 1) / bn, nty = (g.M + bm - 1) / bm;
     const dim3 grid(ntx * nty);

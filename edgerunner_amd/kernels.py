@@ -112,6 +112,17 @@ def flash_attn_f16(q, k, v, heads):
     return o
 
 
+def flash_attn_hh(q, k, v, heads):
+    """The same attention through the LDS-DMA kernel (fp16 q / k / v in HBM, V transposed per head; fp16 output widened to fp32)."""
+    lib = native.load_library()
+    B, N, _ = q.shape
+    M = k.shape[1]
+    o = torch.empty_like(q)
+    native.check(lib.er_k_flash_attn_hh(native.ptr(q), native.ptr(k), native.ptr(v), native.ptr(o), B, heads, N, M, _st()),
+                 "er_k_flash_attn_hh")
+    return o
+
+
 def flash_attn_f32(q, k, v, heads, causal=False):
     """q [B,N,H*D], k/v [B,M,H*D] fp32 -> softmax(q k^T / sqrt(D) [+ causal, key j <= i + M - N]) v in exact fp32 on the
     f32-input matrix cores, no score matrix in HBM (head_dim 64 or 96)."""

@@ -291,6 +291,10 @@ int er_k_flash_attn_f32(const float* q, const float* k, const float* v, float* o
 /* STAGED for round 3 (unmeasured, not on the default path; env ER_PREFILL_ATTN_F16S=1 selects it for the fast-mode prefill):
  * the same attention for head_dim 96 on the fp16 matrix cores with hi/lo-split q and p; k / v must hold
  * fp16-representable values (the fast-mode prefill's scratch does) */
+/* the same attention with q / k / v in fp16 brought in by LDS-DMA (V transposed per head): the unit entry converts and transposes
+ * the fp32 inputs first and widens the fp16 output */
+int er_k_flash_attn_hh(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch, int heads, int n, int m,
+                       void* stream);
 int er_k_flash_attn_f16s(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch, int heads,
                          int n_queries, int m_keys, int causal, void* stream);
 int er_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,

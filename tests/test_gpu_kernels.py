@@ -356,6 +356,10 @@ def test_flash_attn_f16(B, H, N, M):
     p = torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, dim=-1)
     ref = (p @ vh).transpose(1, 2).reshape(B, N, H * 64)
     close(o, ref, 4e-3, 4e-3, "flash attention (fp16 P)")   # P is rounded to fp16 before P.V
+    # the LDS-DMA variant works on the same fp16 roundings of q / k / v / p: equal to the register-staged kernel up to the fp16
+    # rounding of its OUTPUT (the only difference; it feeds an fp16 Linear)
+    o2 = K_.flash_attn_hh(q, k, v, H)
+    assert torch.equal(o2, o.half().float()), f"LDS-DMA attention differs: max {float((o2 - o).abs().max()):.3e}"
 
 
 @pytest.mark.parametrize("B,H,N,M,D,causal", [
