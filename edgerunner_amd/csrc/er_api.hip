@@ -655,13 +655,11 @@ struct StepPlan {   // which kinds to launch (profiling launches one kind at a t
 
 template <typename WT, int KS, int RW, int PRO, int EPI, int NW = ER_NWAVES>
 static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
-    // rows are processed in groups of 4/2/1 (K = 6144 keeps <= 2 rows of input in LDS)
-    const int maxnb = (KS == 1) ? 4 : 2;
+    // rows are processed in groups of up to 4 (one weight stream, 1..4 accumulators per row)
     int b = 0;
     while (b < B) {
         int nb = B - b;
-        nb = nb >= 4 ? 4 : (nb >= 2 ? 2 : 1);
-        if (nb > maxnb) nb = maxnb;
+        nb = nb >= 4 ? 4 : nb;
         GemvArgs g = a;
         if (g.xin) g.xin += (long long)b * K;
         if (g.hout) g.hout += (long long)b * K;
@@ -674,7 +672,8 @@ static hipError_t gemv_groups(GemvArgs a, int B, int K, hipStream_t st) {
         if (g.kcache) g.kcache = (char*)g.kcache + kvb;
         if (g.vcache) g.vcache = (char*)g.vcache + kvb;
         hipError_t e;
-        if (nb == 4) e = launch_gemv<WT, KS, (KS == 1 ? 4 : 2), RW, PRO, EPI, NW>(g, st);
+        if (nb == 4) e = launch_gemv<WT, KS, 4, RW, PRO, EPI, NW>(g, st);
+        else if (nb == 3) e = launch_gemv<WT, KS, 3, RW, PRO, EPI, NW>(g, st);
         else if (nb == 2) e = launch_gemv<WT, KS, 2, RW, PRO, EPI, NW>(g, st);
         else e = launch_gemv<WT, KS, 1, RW, PRO, EPI, NW>(g, st);
         if (e != hipSuccess) return e;

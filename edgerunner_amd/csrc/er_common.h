@@ -47,6 +47,23 @@ __device__ __forceinline__ float block_sum_slot(float v, float* slot, bool write
     return (slot[0] + slot[1]) + (slot[2] + slot[3]);
 }
 
+// NB such sums behind ONE barrier (slot of sum b: slots + stride * b); same per-sum order as block_sum_slot
+template <int NW, int NB>
+__device__ __forceinline__ void block_sum_slots(float (&v)[NB], float* slots, int stride, bool writer) {
+    static_assert(NW == 3 || NW == 4, "3- or 4-wave reductions");
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        v[b] = wave_sum(v[b]);
+        if (writer && (threadIdx.x & 63) == 0) slots[stride * b + (threadIdx.x >> 6)] = v[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float* s = slots + stride * b;
+        v[b] = NW == 3 ? (s[0] + s[1]) + s[2] : (s[0] + s[1]) + (s[2] + s[3]);
+    }
+}
+
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
     constexpr int PT = K / PTPB;   // elements per thread in the prologue
     static_assert(K % PTPB == 0 && (KS == 1 || NW == ER_NWAVES), "prologue / split-K shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;              // [NB][K]
-    float* red = smem + NB * K;    // 64 floats
+    float* xs = smem;              // [NB][K] (PRO_NONE reads its input straight from global memory: no image)
+    float* red = smem + (PRO == PRO_NONE ? 0 : NB * K);    // 64 floats
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int slice = (KS == 1) ? 0 : wid;                 // K-slice this wave reduces
     const bool pro = (NW <= 4) || wid < PW;                // wave-uniform: this wave takes part in the prologue arithmetic
@@ -180,33 +180,49 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
     __builtin_amdgcn_sched_barrier(0);         // keep the whole stream issued before the prologue arithmetic
 
     // ---------------- prologue: build the input vector(s) in LDS (PRO_NONE reads them straight into the
-    // dot-product register layout below: no staging, no barrier)
+    // dot-product register layout below: no staging, no barrier).  The statistics of all NB rows share their barriers: one for
+    // the means, one for the variances (round 2 looped over the rows with two barriers each - at NB = 4 the prologue, repeated
+    // by every workgroup, cost as much as the weight stream: qkv 7.5 us at one row, 15.8 us at four)
+    if (PRO == PRO_EMBED && pro) {
 #pragma unroll
-    for (int b = 0; b < NB && PRO != PRO_NONE; ++b) {
-        if (PRO == PRO_EMBED && pro) {
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int i = 0; i < PT; ++i) v[b][i] += v2[b][i];
+    }
+    if (PRO == PRO_LN) {
+        // each reduction has its own LDS slot (same summation order as block_sum)
+        float s[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            s[b] = 0.f;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) s[b] += pro ? v[b][i] : 0.f;
         }
-        if (PRO == PRO_LN) {
-            // each reduction has its own LDS slot, so it costs one barrier instead of two (same summation order as block_sum)
-            float s = 0.f;
+        block_sum_slots<PW, NB>(s, red, 8, pro);
+        float s2[NB], mean[NB];
 #pragma unroll
-            for (int i = 0; i < PT; ++i) s += pro ? v[b][i] : 0.f;
-            const float mean = block_sum_slot<PW>(s, red + 8 * b, pro) / (float)K;
-            float s2 = 0.f;
+        for (int b = 0; b < NB; ++b) {
+            mean[b] = s[b] / (float)K;
+            s2[b] = 0.f;
 #pragma unroll
-            for (int i = 0; i < PT; ++i) { const float d = (pro ? v[b][i] : 0.f) - mean; s2 = fmaf(d, d, s2); }
-            const float var = block_sum_slot<PW>(s2, red + 8 * b + 4, pro) / (float)K;
-            const float rstd = 1.0f / sqrtf(var + a.eps);
-            if (pro) {
-#pragma unroll
-                for (int i = 0; i < PT; ++i) v[b][i] = (v[b][i] - mean) * rstd * lw[i] + lb[i];
-            }
+            for (int i = 0; i < PT; ++i) { const float d = (pro ? v[b][i] : 0.f) - mean[b]; s2[b] = fmaf(d, d, s2[b]); }
         }
+        block_sum_slots<PW, NB>(s2, red + 4, 8, pro);
         if (pro) {
 #pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float rstd = 1.0f / sqrtf(s2[b] / (float)K + a.eps);
+#pragma unroll
+                for (int i = 0; i < PT; ++i) v[b][i] = (v[b][i] - mean[b]) * rstd * lw[i] + lb[i];
+            }
+        }
+    }
+    if (PRO != PRO_NONE && pro) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
             for (int i = 0; i < PT; ++i) xs[b * K + tid + i * PTPB] = v[b][i];
-            if (PRO != PRO_NONE && a.hout != nullptr && blockIdx.x == 0) {
+            if (a.hout != nullptr && blockIdx.x == 0) {
 #pragma unroll
                 for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * PTPB] = v[b][i];
             }
@@ -214,28 +230,28 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
     }
     if (PRO != PRO_NONE) __syncthreads();
 
-    // ---------------- main: dot the (already in flight) weight rows with the input
-    f32x4 xr[NB][J * XV];      // the EPL inputs matching load j are float4 #(j*64+lane)*XV .. +XV of the slice
+    // ---------------- main: dot the (already in flight) weight rows with the input, ONE batch row's slice in registers at a time
+    // (round 2 held all NB slices at once: 24 VGPRs per row pushed the 2..4-row launches to half the occupancy, so that the grid
+    // no longer fitted the chip in one round - qkv 7.5 us at one row, 15.5 us at four, profiles/r03_batch_table.log).  The
+    // arithmetic per (row, batch row) is unchanged: same per-lane fmaf chain, same butterfly.
+    float acc[RW][NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const float* xsrc = (PRO == PRO_NONE) ? a.xin + (long long)b * K + slice * SL : xs + b * K + slice * SL;
+        f32x4 xr[J * XV];      // the EPL inputs matching load j are float4 #(j*64+lane)*XV .. +XV of the slice
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int u = 0; u < XV; ++u)
-                xr[b][j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
-    }
-
-    float acc[RW][NB];
+                xr[j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int r = 0; r < RW; ++r) {
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < J; ++j) s = dot_w<WT>(w[r][j], &xr[b][j * XV], s);
+            for (int j = 0; j < J; ++j) s = dot_w<WT>(w[r][j], &xr[j * XV], s);
             acc[r][b] = wave_sum(s);
         }
+    }
 
     if (KS == 1) {
         if (lane == 0) {
@@ -270,7 +286,7 @@ inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t st) {
     constexpr int K = KS * 1536;
     const int rows_per_block = (KS == 1) ? NW * RW : RW;
     const int grid = (a.N + rows_per_block - 1) / rows_per_block;
-    const size_t lds = (size_t)(NB * K + 64) * sizeof(float);
+    const size_t lds = (size_t)((PRO == PRO_NONE ? 0 : NB * K) + 64) * sizeof(float);
     hipLaunchKernelGGL((gemv_kernel<WT, KS, NB, RW, PRO, EPI, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
     return hipGetLastError();
 }
