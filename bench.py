@@ -44,7 +44,8 @@ KV_ELEMS_PER_POS = 73_728      # 2 * 24 * 1536
 PREFIX = 2050                  # 2049 condition tokens + BOS
 LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "out_proj_gemv": 24, "fc1_gemv": 24,
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_hbm_summary.json")
+# committed rocprofv3 PMC summaries (scripts/gpu_round3.sh pmc / pmc3): single-row decode kernels, batched (B = 32) decode kernels
+PMC_SUMMARY = {False: os.path.join("profiles", "r03_pmc_hbm_summary.json"), True: os.path.join("profiles", "r03_pmc_hbm_config3_summary.json")}
 # the single-GPU configurations of BASELINE.json (configs[0] is the CPU path = cpu_baseline; configs[4] = dit_front_end_fp16)
 CONFIGS = {
     1: {"name": "BASELINE configs[1]", "batch": 1, "num_face": 1000, "mode": "greedy", "precision": "fp32"},
@@ -105,12 +106,12 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def pmc_traffic(kind, kernel_names, at_len):
-    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes (profiles/r02_pmc_hbm_summary.json:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes; separate --pmc runs, scripts/gpu_pmc.sh).  Counters cannot
-    be read inside the timed process.  The attention passes run at a recorded context length (the PMC run starts its
+def pmc_traffic(kind, kernel_names, at_len, batched=False):
+    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes (profiles/r03_pmc_hbm_*summary.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes; separate --pmc runs, scripts/gpu_round3.sh pmc / pmc3).  Counters
+    cannot be read inside the timed process.  The attention passes run at a recorded context length (the PMC run starts its
     decode at --resume-len); its bytes are scaled linearly to `at_len` keys, the length `bytes_per_launch` is quoted at."""
-    path = os.path.join(ROOT, PMC_SUMMARY)
+    path = os.path.join(ROOT, PMC_SUMMARY[bool(batched)])
     try:
         doc = json.load(open(path))
         ks = doc["kernels"]
@@ -122,7 +123,7 @@ def pmc_traffic(kind, kernel_names, at_len):
             if l_pmc > 0:
                 b = b * at_len / l_pmc
                 note = f" (attention measured at mean context {l_pmc:.0f}, scaled x{at_len / l_pmc:.4f} to {at_len} keys)"
-        return {"bytes": round(b), "source": PMC_SUMMARY + note}
+        return {"bytes": round(b), "source": PMC_SUMMARY[bool(batched)] + note}
     except Exception:
         return {}
 
@@ -403,7 +404,7 @@ def main(argv=None):
     ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
     bytes_per_token = W_ELEMS * esz / B + KV_ELEMS_PER_POS * mean_L * esz
     names = kernel_names(args.precision, B > 4)
-    traffic = pmc_traffic(dom, names.get(dom, []), L_ref)
+    traffic = pmc_traffic(dom, names.get(dom, []), L_ref, batched=B > 4)
     layer_us = sum(prof[k]["avg_us"] for k in ("qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv", "fc1_gemv", "fc2_gemv"))
     roofline = {
         "bound": "hbm", "kernel": dom, "kernel_name": (names.get(dom) or ["?"])[0], "achieved": round(ach, 1),
@@ -413,7 +414,7 @@ def main(argv=None):
         "context_len_at_measurement": L_ref,
         "note": f"run-average: mean launch duration over {NS} contexts spread over the timed run (contexts {L0 + 1}..{L0 + T}) and "
                 "the algorithmic bytes of one launch at the mean context length; reproduce with scripts/roofline_from_rocprof.py "
-                "on profiles/r02_*_kernel_stats.csv",
+                "on profiles/r03_*_kernel_stats.csv",
         "context_sweep": ends,
         "per_layer_kernel_sum_us": round(layer_us, 2),
         "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (max(v["avg_us"], 1e-9) * 1e-6) / 1e9, 1),
