@@ -115,7 +115,12 @@ def pmc_traffic(kind, kernel_names, at_len, batched=False):
     try:
         doc = json.load(open(path))
         ks = doc["kernels"]
-        k = next(ks[n] for n in kernel_names if n in ks)
+        def lookup(n):      # rocprofv3 leaves kernels with _Float16 template arguments mangled: match base name + element type
+            if n in ks:
+                return ks[n]
+            base, half = n.split("<")[0], "_Float16" in n
+            return next((v for m, v in ks.items() if m.startswith("_Z") and base in m and (("DF16_" in m) == half)), None)
+        k = next(v for v in (lookup(n) for n in kernel_names) if v is not None)
         b = k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)
         note = ""
         if kind == "attn_decode":
@@ -417,7 +422,7 @@ def main(argv=None):
                 "on profiles/r03_*_kernel_stats.csv",
         "context_sweep": ends,
         "per_layer_kernel_sum_us": round(layer_us, 2),
-        "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (max(v["avg_us"], 1e-9) * 1e-6) / 1e9, 1),
+        "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1) if v["avg_us"] > 0 else 0.0,
                         "us_per_token": round(per_token_us[k], 2)} for k, v in prof.items()},
         "whole_step": {"bytes_per_token": bytes_per_token,
                        "achieved_GBps": round(decode_only / world * bytes_per_token / 1e9, 1),

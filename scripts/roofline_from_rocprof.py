@@ -29,6 +29,12 @@ def load_stats(path):
 def find(stats, needle):
     hits = [(n, v) for n, v in stats.items() if needle in n]
     if not hits:
+        # rocprofv3 leaves kernels with _Float16 template arguments MANGLED (_ZN2er18attn_stream_kernelIDF16_Li96ELi2EEE...):
+        # match the base name and the element type instead
+        base = needle.split("<")[0]
+        half = "_Float16" in needle
+        hits = [(n, v) for n, v in stats.items() if n.startswith("_Z") and base in n and (("DF16_" in n) == half)]
+    if not hits:
         return None, None
     return max(hits, key=lambda kv: kv[1]["calls"])
 
