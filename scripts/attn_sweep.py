@@ -25,7 +25,7 @@ T = int(os.environ.get("SWEEP_T", "4000"))
 PRECISION = os.environ.get("SWEEP_PRECISION", "fp32")
 CONTEXTS = json.loads(os.environ.get("SWEEP_CONTEXTS", "[2176, 3176, 3926, 4050, 4176, 5176, 5926]"))
 CONFIGS = [dict()] + [dict(c) for c in json.loads(os.environ.get("SWEEP_CONFIGS", "[]"))]
-KNOBS = ["ER_ATTN_GRID_HS", "ER_ATTN_V", "ER_ATTN_V_BATCHED", "ER_COMBINE_V", "ER_DECODE_V", "ER_ATTN_STEPS", "ER_NW_QKV"]
+KNOBS = ["ER_ATTN_V_BATCHED", "ER_DECODE_V", "ER_NW_QKV"]
 
 
 def main():

@@ -25,4 +25,4 @@ for B in Bs:
         torch.cuda.synchronize(); t = time.perf_counter()
         m.generate(pcs, 1000, tokenizer=object(), max_new_tokens=4, min_new_tokens=4)
         torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t) * 1e3)
-    print(f"{prec} F16S_BK={os.environ.get('ER_F16S_BK', '32')} B {B}: encode + prefill + 4 steps {best:.1f} ms, {best / B:.2f} ms per sample", flush=True)
+    print(f"{prec} B {B}: encode + prefill + 4 steps {best:.1f} ms, {best / B:.2f} ms per sample", flush=True)

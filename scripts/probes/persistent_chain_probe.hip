@@ -2,12 +2,11 @@
 // all 24 layers with an XCD-hierarchical grid barrier per phase and the NEXT phase's weights prefetched into registers
 // BEFORE the barrier wait (the experiment VERDICT r1 asked to redo with the guide's barrier instead of the single-counter
 // probe).  (C) is (B) with the prefetch issued after the barrier, isolating what the prefetch buys.
-// (D) [added at the end of round 2, NOT YET RUN] replaces the barrier + acquire of (B) by a data-tagged all-gather: the 1536
-// floats the next phase reads travel as 8-byte {value, phase tag} granules, each written by ONE 64-bit relaxed agent-scope
-// atomic store (sc1 write-through) and swept by the sync wave of every CU with 64-bit relaxed agent-scope atomic loads until
-// all 1536 tags carry the phase number (MI355X_MICROARCH.md price list: handoff / allgather rows), then handed to the compute
-// waves through LDS.  Two granule buffers by phase parity: a producer of phase p+2 cannot run before every CU has consumed
-// phase p.  Spins are bounded; a give-up is reported, never a hang.
+// (D) [round 2's staged variant: the barrier replaced by a data-tagged all-gather of 8-byte {value, phase tag} granules] was run in
+// round 3 - 74.6 us per layer, the slowest of all (profiles/r03_persistent_chain_probe_D.log) - and removed from this file.
+// (F) replaces the barrier tree of (B) by flat arrival counters sharded per XCD that every CU polls itself, the next phase's
+// input read with sc1 loads - no fence at all: 56.2 us per layer (profiles/r03_persistent_chain_probe_F.log): the poll and the
+// input read queue behind the CU's own prefetched weight stream.
 //
 // The layer keeps the real byte volumes and the real all-to-all dependency structure of the B = 1 fp32 decode layer
 // (every phase needs the WHOLE output vector of the previous one), with simplified arithmetic: five GEMVs over rows of
@@ -103,13 +102,12 @@ constexpr int PW = 16, CW = PW - 1, PT = PW * 64, RMAX = 3;   // waves per workg
 // grid = one workgroup per CU (the 100 KB dynamic LDS request forces one per CU).  Wave PW-1 is the "sync" wave: it
 // publishes the workgroup's outputs (write-through sc1 stores), drains them, runs the grid barrier and the acquire; the
 // 15 compute waves meanwhile have the next phase's weight rows in flight and park on the workgroup barrier.
-// MODE 0: barrier, prefetch before it (B); 1: barrier, prefetch after it (C); 2: tagged all-gather, prefetch before it (D)
-constexpr int GRAN_N = K;                      // granules per phase: the 1536 floats the next phase reads
+// MODE 0: barrier, prefetch before it (B); 1: barrier, prefetch after it (C); 3: flat sharded counters + sc1 reads (F)
 template <int MODE>
 __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict__ Wall, float* xbuf0, float* xbuf1, BarState* s, int layers,
                                                         unsigned long long* gran0, unsigned long long* gran1) {
     constexpr bool PREFETCH = MODE != 1;
-    constexpr bool GATHER = MODE == 2;
+    constexpr bool GATHER = false;
     constexpr bool FLAT = MODE == 3;           // (F): sharded arrival counters polled by every CU, x read with sc1 loads - no fence, no barrier tree
     extern __shared__ float ylds[];            // [64] outputs of this workgroup in the current phase; [256 ..] the gathered x (MODE 2)
     float* xs = ylds + 256;
@@ -177,45 +175,7 @@ __global__ __launch_bounds__(PT) void persistent_kernel(const float* __restrict_
             if (PREFETCH && gp + 1 < total) issue(gp + 1);     // in flight across the grid barrier
         }
         __syncthreads();                                        // ylds complete
-        if (wid == CW && GATHER) {
-            // (D) publish: every row to yout (the final check reads it), the rows the next phase reads also as tagged granules
-            unsigned long long* gw = ((gp + 1) & 1) ? gran1 : gran0;
-            if (lane < 48) {
-                const int row = cu + ncu * lane;
-                if (row < N) {
-                    const float v = ylds[lane];
-                    __hip_atomic_store((gf32*)(yout + row), v, RLX_AGENT);
-                    if (row < GRAN_N && gp + 1 < total)
-                        __hip_atomic_store((gu64*)(gw + row), ((unsigned long long)(unsigned)(gp + 1) << 32) | (unsigned long long)__float_as_uint(v), RLX_AGENT);
-                }
-            }
-            if (gp + 1 < total) {
-                // gather: lane l owns granules l, l + 64, ... (24 per lane); re-read only what has not arrived yet
-                constexpr int PER = GRAN_N / 64;
-                unsigned pending = (1u << PER) - 1u;
-                unsigned spins = 0;
-                bool gave_up = false;
-                while (__any(pending != 0u)) {
-#pragma unroll
-                    for (int j = 0; j < PER; ++j) {
-                        if (pending & (1u << j)) {
-                            const unsigned long long g = __hip_atomic_load((gu64*)(gw + lane + 64 * j), RLX_AGENT);
-                            if ((unsigned)(g >> 32) == (unsigned)(gp + 1)) {
-                                xs[lane + 64 * j] = __uint_as_float((unsigned)g);
-                                pending &= ~(1u << j);
-                            }
-                        }
-                    }
-                    if (++spins > SPIN_LIMIT / 64 || __hip_atomic_load((gu32*)&s->error[0], RLX_AGENT) != 0) {
-                        __hip_atomic_store((gu32*)&s->error[0], 1u, RLX_AGENT);
-                        gave_up = true;
-                        break;
-                    }
-                    if (__any(pending != 0u)) __builtin_amdgcn_s_sleep(1);
-                }
-                (void)gave_up;
-            }
-        } else if (wid == CW && FLAT) {
+        if (wid == CW && FLAT) {
             // (F) publish write-through, drain, ONE arrival on shard cu % 8, poll the 8 shards, fetch x past L1 (sc1) into LDS
             if (lane < 48) {
                 const int row = cu + ncu * lane;
@@ -359,26 +319,21 @@ int main(int argc, char** argv) {
     const size_t lds = 100 * 1024;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persistent_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    unsigned long long *g0, *g1;
-    CHECK(hipMalloc(&g0, GRAN_N * sizeof(unsigned long long)));
-    CHECK(hipMalloc(&g1, GRAN_N * sizeof(unsigned long long)));
-    const int vmask = argc > 1 ? atoi(argv[1]) : 15;      // bit v selects variant v: 1 = (B), 2 = (C), 4 = (D), 8 = (F)
+    unsigned long long *g0 = nullptr, *g1 = nullptr;
+    const int vmask = argc > 1 ? atoi(argv[1]) : 11;      // bit v selects variant v: 1 = (B), 2 = (C), 8 = (F)  [4 = (D), removed]
     for (int variant = 0; variant < 4; ++variant) {
-        if (!(vmask & (1 << variant))) continue;
+        if (!(vmask & (1 << variant)) || variant == 2) continue;
         const bool prefetch = variant != 1;
         float best = 1e9f;
         bool ok = true, timeout = false;
         for (int r = 0; r < 6; ++r) {
             reset_x();
             CHECK(hipMemsetAsync(bs, 0, sizeof(BarState), st));
-            CHECK(hipMemsetAsync(g0, 0, GRAN_N * sizeof(unsigned long long), st));     // tag 0 never matches a phase number (1..)
-            CHECK(hipMemsetAsync(g1, 0, GRAN_N * sizeof(unsigned long long), st));
             CHECK(hipEventRecord(e0, st));
             if (variant == 0) hipLaunchKernelGGL(persistent_kernel<0>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
             else if (variant == 1) hipLaunchKernelGGL(persistent_kernel<1>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
-            else if (variant == 2) hipLaunchKernelGGL(persistent_kernel<2>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
+            else if (variant == 2) continue;
             else hipLaunchKernelGGL(persistent_kernel<3>, dim3(ncu), dim3(PT), lds, st, W, xa, xb, bs, NL, g0, g1);
             CHECK(hipGetLastError());
             CHECK(hipEventRecord(e1, st));

@@ -17,8 +17,7 @@ from edgerunner_amd.options import config_defaults  # noqa: E402
 
 T = int(os.environ.get("TUNE_TOKENS", "1000"))
 CONFIGS = [dict()] + [dict(c) for c in json.loads(os.environ.get("TUNE_CONFIGS", "[]"))]
-KNOBS = ["ER_RW_QKV", "ER_RW_FC1", "ER_RW_FC2", "ER_RW_OUT", "ER_ATTN_STEPS", "ER_NO_GRAPH", "ER_PROF_LAYERS", "ER_ATTN_V", "ER_COMBINE_V",
-         "ER_NW_QKV", "ER_NW_FC1", "ER_NW_OUT", "ER_PREFILL_ATTN", "ER_DEBUG_KV_FLAT", "ER_ATTN_GRID_HS", "ER_PREFILL_GEMM", "ER_DECODE_V"]
+KNOBS = ["ER_NO_GRAPH", "ER_NW_QKV", "ER_NW_FC1", "ER_DECODE_V", "ER_ATTN_V_BATCHED", "ER_PREFILL_ATTN_F16S", "ER_FORCE_BATCHED", "ER_BATCHED_VALU"]
 PRECISION = os.environ.get("TUNE_PRECISION", "fp32")
 
 
