@@ -45,6 +45,8 @@ struct er_dit_ctx {
     Buf x16, att16, g16;
     // ... and q / k / v in fp16 with V transposed, for the LDS-DMA attention (k_flash_attn.h, flash_attn_hh_kernel)
     Buf qkv16, vt16, q2_16, k2_16, v2tmp16, v2t16;
+    Buf gates;                             // [layer][2][B][C]: gate_msa / gate_mlp rows of every layer (one launch per forward)
+    const float** sst_ptrs = nullptr;      // device array of the layers' scale_shift_table pointers
     int kv2_mp = 0;                        // padded key count of the cross-attention V^T rows
     bool geglu_perm_valid = false;
 };
@@ -137,7 +139,7 @@ extern "C" int er_dit_destroy(er_dit_ctx* c) {
         if (b->p) hipFree(b->p);
     for (Buf* b : {&c->x, &c->qkv, &c->att, &c->q2, &c->kv2, &c->u, &c->g, &c->sc, &c->tin, &c->temb0, &c->temb1, &c->temb,
                    &c->tsil, &c->tada, &c->gate, &c->t_dev, &c->xin, &c->pred, &c->czero, &c->ctmp, &c->x16, &c->att16, &c->g16,
-                   &c->qkv16, &c->vt16, &c->q2_16, &c->k2_16, &c->v2tmp16, &c->v2t16})
+                   &c->qkv16, &c->vt16, &c->q2_16, &c->k2_16, &c->v2tmp16, &c->v2t16, &c->gates})
         if (b->p) hipFree(b->p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -386,7 +388,14 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     static const bool no_flash = getenv("ER_DIT_NO_FLASH") != nullptr;
     const bool flash = c->fast && D == FA_D && !no_flash;
     if (!flash) ERCHK(ensure(c->sc, (size_t)H * N * ldS));
-    ERCHK(ensure(c->gate, (size_t)B * C));
+    ERCHK(ensure(c->gates, (size_t)g.num_layers * 2 * B * C));
+    if (!c->sst_ptrs) {
+        std::vector<const float*> hp;
+        for (auto& L : c->layers) hp.push_back(L.sst);
+        HIPCHK(hipMalloc((void**)&c->sst_ptrs, hp.size() * sizeof(float*)));
+        c->owned.push_back((void*)c->sst_ptrs);
+        HIPCHK(hipMemcpy((void*)c->sst_ptrs, hp.data(), hp.size() * sizeof(float*), hipMemcpyHostToDevice));
+    }
     // fp16 activations for the LDS-DMA GEMM (all K of this path are multiples of 64 except none: C = 1024, 4C = 4096)
     const bool hh = flash && C % 64 == 0;
     if (hh) {
@@ -408,6 +417,12 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     _Float16* q2_16 = hh ? reinterpret_cast<_Float16*>(c->q2_16.p) : nullptr;
     if (hh && (N % 64 != 0 || c->kv2_mp != (M + 63) / 64 * 64)) return fail(ER_ERR_INVALID, "dit: fp16 attention operands are not prepared (latent_size %% 64, cross K/V)");
     ERCHK(dit_time_embed(c, B, st));
+    {
+        const long long ng = (long long)g.num_layers * 2 * B * C;
+        hipLaunchKernelGGL(adaln_gate_all_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, c->sst_ptrs, c->tada.p, c->gates.p,
+                           g.num_layers, B, C);
+        HIPRET(hipGetLastError());
+    }
     float* x = c->x.p;
     // x = proj_in(x) + pos_embed                                                  dit.py:177-180
     HIPRET(dlin(c, xin, LD, c->proj_in_w, c->proj_in_b, x, C, R, C, LD, nullptr, 0, nullptr, 1, st));
@@ -446,11 +461,11 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
             }
         }
         }
-        hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 2);
-        HIPRET(hipGetLastError());
+        const float* gate_msa = c->gates.p + ((size_t)l * 2) * B * C;
+        const float* gate_mlp = gate_msa + (size_t)B * C;
         // (the fp16 copy of the new x is the A operand of the cross-attention query projection)
-        if (hh) HIPRET(dlin16(c, att16, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, x16, st));
-        else HIPRET(dlin(c, c->att.p, C, L.o_w, L.o_b, x, C, R, C, C, x, C, c->gate.p, N, st));
+        if (hh) HIPRET(dlin16(c, att16, C, L.o_w, L.o_b, x, C, R, C, C, x, C, gate_msa, N, x16, st));
+        else HIPRET(dlin(c, c->att.p, C, L.o_w, L.o_b, x, C, R, C, C, x, C, gate_msa, N, st));
         // x = x + attn2(x, c)                                                       dit.py:135
         if (hh) HIPRET(dlin16(c, x16, C, L.q2_w, L.q2_b, nullptr, C, R, C, C, nullptr, 0, nullptr, 1, q2_16, st));
         else HIPRET(dlin(c, x, C, L.q2_w, L.q2_b, c->q2.p, C, R, C, C, nullptr, 0, nullptr, 1, st));
@@ -492,10 +507,8 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
             hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid((long long)R * 4 * C)), dim3(ER_WG), 0, st, c->u.p, c->g.p, (long long)R, 4 * C);
             HIPRET(hipGetLastError());
         }
-        hipLaunchKernelGGL(adaln_gate_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, L.sst, c->tada.p, c->gate.p, B, C, 5);
-        HIPRET(hipGetLastError());
-        if (hh) HIPRET(dlin16(c, g16, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, c->gate.p, N, nullptr, st));
-        else HIPRET(dlin(c, c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, c->gate.p, N, st));
+        if (hh) HIPRET(dlin16(c, g16, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, gate_mlp, N, nullptr, st));
+        else HIPRET(dlin(c, c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, gate_mlp, N, st));
     }
     // shift, scale = scale_shift_table + t_emb; x = norm_out(x) * (1 + scale) + shift; proj_out     dit.py:190-194
     HIPRET(dit_ln_mod(x, x, R, N, c->sst2, c->temb.p, (long long)C, 0, 0, 1, st, x16));

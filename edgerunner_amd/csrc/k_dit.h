@@ -16,31 +16,42 @@ __global__ __launch_bounds__(ER_WG) void ln_modulate_rows_kernel(const float* x,
                                                                  const float* table, const float* tvec, long long t_bstride,
                                                                  long long t_cstride, int shift_idx, int scale_idx, float eps,
                                                                  _Float16* y16) {
-    constexpr int C = CPL * 64;
+    constexpr int C = CPL * 64, V = CPL / 4;        // a lane holds V float4: columns 4 * (lane + 64 i) .. + 3 (16-byte accesses throughout)
+    static_assert(CPL % 4 == 0, "row width must be a multiple of 256");
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * ER_NWAVES + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int b = r / rows_per_batch;
-    const float* xr = x + (long long)r * C;
-    float v[CPL];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long long)r * C);
+    f32x4 v[V];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+    for (int i = 0; i < V; ++i) { v[i] = xr[lane + 64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
     const float mean = wave_sum(s) / (float)C;
     float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { const float d = v[i] - mean; s2 = fmaf(d, d, s2); }
+    for (int i = 0; i < V; ++i) {
+        const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+        s2 = fmaf(d0, d0, s2); s2 = fmaf(d1, d1, s2); s2 = fmaf(d2, d2, s2); s2 = fmaf(d3, d3, s2);
+    }
     const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)C + eps);
     const float* tb = tvec + (long long)b * t_bstride;
-    float* yr = y + (long long)r * C;
+    f32x4* yr = reinterpret_cast<f32x4*>(y + (long long)r * C);
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const int c = lane + 64 * i;
-        const float scale = table[scale_idx * C + c] + tb[scale_idx * t_cstride + c];
-        const float shift = table[shift_idx * C + c] + tb[shift_idx * t_cstride + c];
-        const float o = (v[i] - mean) * rstd * (1.0f + scale) + shift;
-        yr[c] = o;
-        if (y16) y16[(long long)r * C + c] = (_Float16)o;
+    for (int i = 0; i < V; ++i) {
+        const int c4 = lane + 64 * i;
+        const f32x4 sc = reinterpret_cast<const f32x4*>(table + scale_idx * C)[c4] + reinterpret_cast<const f32x4*>(tb + scale_idx * t_cstride)[c4];
+        const f32x4 sh = reinterpret_cast<const f32x4*>(table + shift_idx * C)[c4] + reinterpret_cast<const f32x4*>(tb + shift_idx * t_cstride)[c4];
+        f32x4 o;
+        o.x = (v[i].x - mean) * rstd * (1.0f + sc.x) + sh.x;
+        o.y = (v[i].y - mean) * rstd * (1.0f + sc.y) + sh.y;
+        o.z = (v[i].z - mean) * rstd * (1.0f + sc.z) + sh.z;
+        o.w = (v[i].w - mean) * rstd * (1.0f + sc.w) + sh.w;
+        yr[c4] = o;
+        if (y16) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            reinterpret_cast<h4*>(y16 + (long long)r * C)[c4] = (h4){(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+        }
     }
 }
 
@@ -50,6 +61,17 @@ __global__ void adaln_gate_kernel(const float* table, const float* tada, float* 
     if (i >= B * C) return;
     const int b = i / C, c = i - b * C;
     out[i] = table[idx * C + c] + tada[((long long)b * 6 + idx) * C + c];
+}
+
+// the gates of EVERY layer in one launch: out[(layer * 2 + which) * B * C + b * C + c], which 0 -> chunk 2 (gate_msa), 1 -> chunk 5
+// (gate_mlp); tables = device array of the layers' scale_shift_table pointers.  (One launch instead of two ~4 us launches per layer.)
+__global__ void adaln_gate_all_kernel(const float* const* tables, const float* tada, float* out, int layers, int B, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)B * C;
+    if (i >= per * 2 * layers) return;
+    const int lw = (int)(i / per), l = lw >> 1, idx = (lw & 1) ? 5 : 2;
+    const int r = (int)(i - lw * per), b = r / C, c = r - b * C;
+    out[i] = tables[l][idx * C + c] + tada[((long long)b * 6 + idx) * C + c];
 }
 
 // Timesteps(256) (dit.py:45-77): emb[b] = [sin(t*w_k), cos(t*w_k)], w_k = exp(-ln(10000) * k / 128)

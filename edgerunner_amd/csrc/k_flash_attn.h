@@ -100,15 +100,25 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f16_kernel(FlashArgs a) {
         }
         // online softmax for query li
         float mloc = -INFINITY;
+        if (kbase + FA_KT <= a.M) {                  // wave-uniform: only the last tile can hold keys beyond M
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float s = key < a.M ? st[kb][r] * sl2 : -INFINITY;      // log2 units: exp(x) = exp2(x log2 e)
-                st[kb][r] = s;
-                mloc = fmaxf(mloc, s);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    st[kb][r] *= sl2;                // log2 units: exp(x) = exp2(x log2 e)
+                    mloc = fmaxf(mloc, st[kb][r]);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float s = key < a.M ? st[kb][r] * sl2 : -INFINITY;
+                    st[kb][r] = s;
+                    mloc = fmaxf(mloc, s);
+                }
+        }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // m_run = -inf on the first tile -> 0
@@ -287,15 +297,25 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
             }
         }
         float mloc = -INFINITY;
+        if (kbase + FA_KT <= a.M) {                  // wave-uniform: only the last tile can hold keys beyond M
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float s = key < a.M ? st[kb][r] * sl2 : -INFINITY;      // log2 units: exp(x) = exp2(x log2 e)
-                st[kb][r] = s;
-                mloc = fmaxf(mloc, s);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    st[kb][r] *= sl2;                // log2 units: exp(x) = exp2(x log2 e)
+                    mloc = fmaxf(mloc, st[kb][r]);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float s = key < a.M ? st[kb][r] * sl2 : -INFINITY;
+                    st[kb][r] = s;
+                    mloc = fmaxf(mloc, s);
+                }
+        }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
