@@ -514,7 +514,7 @@ def main(argv=None):
                     "A GPU/CPU ratio says nothing about kernel quality - the roofline fraction does."}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -19,6 +19,12 @@ import torch
 import torch.distributed as dist
 
 
+def _collectives_on() -> bool:
+    """Collectives run when there is more than one rank - or, for the single-GPU smoke test of the RCCL path
+    (tests/test_gpu_scripts.py), when ER_DIST_FORCE=1 keeps them on in a one-rank group."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("ER_DIST_FORCE") == "1")
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Sample i runs on rank i mod world (block-cyclic keeps per-rank work balanced)."""
     return list(range(rank, n_items, world))
@@ -31,7 +37,7 @@ def env_rank_world() -> Tuple[int, int, int]:
 def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """One process per GPU, rendezvous from the torchrun env (MASTER_ADDR must be 127.0.0.1 on this pool)."""
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("ER_DIST_FORCE") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -56,7 +62,7 @@ def pack_streams(streams: Sequence[np.ndarray], rows: int, width: int, pad: int 
 def gather_token_streams(local_streams: Sequence[np.ndarray], n_items: int, device=None, pad: int = 0) -> List[np.ndarray]:
     """All ranks contribute the streams of their ``shard_indices``; every rank gets the
     full list back in global sample order.  One all-reduce (max length) + one all-gather."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return [np.asarray(s) for s in local_streams]
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = shard_indices(n_items, rank, world)
@@ -80,12 +86,12 @@ def gather_token_streams(local_streams: Sequence[np.ndarray], n_items: int, devi
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device=None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives_on():
         return value
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

@@ -159,6 +159,8 @@ def main(argv=None):
         np.savez(f"{opt.workspace}/tokens_all.npz", **{k: g - 3 for k, g in zip(index, gathered)})
         print(f"[INFO] {len(jobs)} jobs over {world} rank(s); token streams gathered into {opt.workspace}/tokens_all.npz")
     D.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -140,6 +140,33 @@ def test_infer_py_cond_mode_none(tmp_path):
         assert not (out / "x_pc.obj").exists()
 
 
+def test_rccl_code_path_on_one_gpu(arae_ckpt, tmp_path):
+    """The N > 1 exchange (dist.py: all-reduce of the width, all_gather_into_tensor of the packed streams, barrier, max-over-ranks)
+    has no multi-GPU box to run on from here; ER_DIST_FORCE=1 keeps those collectives ON in a ONE-rank `nccl` (= RCCL) group, so at
+    least the RCCL initialisation, dtypes and device placement of every call execute on real hardware: infer.py end to end, then the
+    gathered archive must equal the per-job files."""
+    from edgerunner_amd import weights as W
+    opt, sd, ckpt = arae_ckpt
+    inp = tmp_path / "a.npy"
+    np.save(inp, W.synthetic_point_cloud(0, 512)[0].numpy())
+    out = tmp_path / "out"
+    env = {"ER_DIST_FORCE": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533",
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    log = run_script("infer.py", ["ArAE", "--num_layers", 2, "--resume", ckpt, "--test_path", inp, "--generate_mode", "greedy",
+                                  "--test_num_face", 1000, 2000, "--test_max_seq_length", 32, "--workspace", out], env)
+    assert "token streams gathered" in log
+    allz = dict(np.load(out / "tokens_all.npz"))
+    for nf in (1000, 2000):
+        assert np.array_equal(allz[f"a_0_{nf}f"], np.load(out / f"a_0_{nf}f_tokens.npy"))
+    # bench.py's plumbing (barrier + max-over-ranks + gather) in the same one-rank RCCL group
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--layers", "2", "--tokens", "32",
+                        "--cpu-steps", "0", "--no-fast-extra"], env={**os.environ, **env, "MASTER_PORT": "29534"}, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    assert '"n_gpus": 1' in line and '"value"' in line
+
+
 def test_lmm_half_selects_fp16_context_or_fails_loudly(arae_ckpt):
     from edgerunner_amd import native
     from edgerunner_amd.models import LMM
