@@ -132,6 +132,7 @@ struct er_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
+    Buf p_hi, p_lo;           // fast-mode prefill: hi / lo fp16 halves of the activation a Linear is about to read (LDS-DMA GEMM, split form)
     Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp, e_ids, e_stage;
 };
 
@@ -274,7 +275,7 @@ extern "C" int er_destroy(er_ctx* c) {
     hipDeviceSynchronize();
     free_kv(c);
     for (void* p : c->owned) hipFree(p);
-    for (Buf* b : {&c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->p_qkv, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
+    for (Buf* b : {&c->p_hi, &c->p_lo, &c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->p_qkv, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
                    &c->e_q, &c->e_sc, &c->e_att, &c->e_l, &c->e_ln, &c->e_u, &c->e_g, &c->e_lat, &c->e_tmp, &c->e_ids, &c->e_stage})
         if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -905,12 +906,38 @@ static hipError_t linear_h(const float* A, int lda, const _Float16* W, const flo
     return launch_gemm_f16s(g, st);
 }
 
+// the same product through the LDS-DMA kernel (k_gemm.h, split form): the fp32 activation is split into hi / lo fp16 arrays by one
+// streaming pass, then both A images and the weight tile reach LDS by DMA.  K % 64 == 0 (1536 / 6144 on the prefill path);
+// same split and MFMA order as linear_h (fast-mode logits unchanged to the last digit); used for small M only (see the body)
+static int linear_hs(er_ctx* c, const float* A, int lda, const _Float16* W, const float* bias, float* C, int ldc, int M, int N, int K,
+                     bool relu, const float* resid, int ldr, hipStream_t st);
+
 #define HIPRET(expr)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess)                                                                 \
             return fail(ER_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
     } while (0)
+
+static int linear_hs(er_ctx* c, const float* A, int lda, const _Float16* W, const float* bias, float* C, int ldc, int M, int N, int K,
+                     bool relu, const float* resid, int ldr, hipStream_t st) {
+    // measured (profiles/r03_prefill_fast_gemm.log): with its 64-row tiles (two A images per stage) and the extra split pass the
+    // LDS-DMA form wins for ONE prefix (encode + prefill 24.2 -> 23.1 ms) and loses to the register-staged 128 x 128 kernel from
+    // 8 prefixes on (13.4 -> 13.8 ms per sample at B = 8, 12.65 -> 13.1 at B = 32): used up to two prefixes
+    if (K % XBK != 0 || M > 4608) { HIPRET(linear_h(A, lda, W, bias, C, ldc, M, N, K, relu, resid, ldr, st)); return 0; }
+    ERCHK(ensure(c->p_hi, (size_t)M * K / 2 + 8));
+    ERCHK(ensure(c->p_lo, (size_t)M * K / 2 + 8));
+    _Float16* hi = reinterpret_cast<_Float16*>(c->p_hi.p);
+    _Float16* lo = reinterpret_cast<_Float16*>(c->p_lo.p);
+    hipLaunchKernelGGL(split_rows_f16_kernel, dim3(ew_grid((long long)M * K / 4)), dim3(ER_WG), 0, st, A, hi, lo, (long long)M, K, lda);
+    HIPRET(hipGetLastError());
+    GemmArgs g = gemm_args_default();
+    g.A = reinterpret_cast<const float*>(hi); g.a_lo = lo; g.B = reinterpret_cast<const float*>(W); g.C = C; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = ldc; g.ldr = ldr;
+    g.relu = relu ? 1 : 0;
+    HIPRET(launch_gemm_hh_split(g, st));
+    return 0;
+}
 
 // softmax(Q K^T / sqrt(D)) V for one sample, all heads; scores live in `sc` ([H][N][ldS]).
 static int attention_full(const float* Q, int ldq, const float* Kp, int ldk, long long k_hstride, const float* Vp, int ldv,
@@ -1105,7 +1132,7 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
             // the cache and in the scratch the prefix attention reads
             ERCHK(ensure(c->p_qkv, (size_t)M * 3 * H));
             float* qkv = c->p_qkv.p;
-            HIPRET(linear_h(h, H, L.wqkv_h, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
+            ERCHK(linear_hs(c, h, H, L.wqkv_h, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
             hipLaunchKernelGGL(kv_scatter_half_kernel, dim3(ew_grid((long long)M * 2 * H)), dim3(ER_WG), 0, st, qkv,
                                (_Float16*)kc, (_Float16*)vc, M, S, H, D, c->Lcap, c->kv_bstride);
             HIPRET(hipGetLastError());
@@ -1123,13 +1150,13 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
         }
         // y = h + out_proj(a); h1 = LN1(y)                               modeling_opt.py:232, 272-274
         const bool hs = c->fast;
-        if (hs) HIPRET(linear_h(a, H, L.wo_h, L.bo, y, H, M, H, H, false, h, H, st));
+        if (hs) ERCHK(linear_hs(c, a, H, L.wo_h, L.bo, y, H, M, H, H, false, h, H, st));
         else HIPRET(linear(a, H, L.wo, L.bo, y, H, M, H, H, false, h, H, st));
         HIPRET(launch_layernorm(y, L.ln1w, L.ln1b, h, M, H, H, H, g.ln_eps, st));
         // y = h1 + fc2(relu(fc1(h1))); h = LN2(y)                        modeling_opt.py:281-288
         if (hs) {
-            HIPRET(linear_h(h, H, L.w1_h, L.b1, f, I, M, I, H, true, nullptr, 0, st));
-            HIPRET(linear_h(f, I, L.w2_h, L.b2, y, H, M, H, I, false, h, H, st));
+            ERCHK(linear_hs(c, h, H, L.w1_h, L.b1, f, I, M, I, H, true, nullptr, 0, st));
+            ERCHK(linear_hs(c, f, I, L.w2_h, L.b2, y, H, M, H, I, false, h, H, st));
         } else {
             HIPRET(linear(h, H, L.w1, L.b1, f, I, M, I, H, true, nullptr, 0, st));
             HIPRET(linear(f, I, L.w2, L.b2, y, H, M, H, I, false, h, H, st));
@@ -1558,10 +1585,24 @@ extern "C" int er_k_gemm_hh(const float* a, const void* w, const float* bias, co
 extern "C" int er_k_gemm_f16s(const float* a, const void* w, const float* bias, const float* resid, float* cc, int m, int n, int k,
                               int lda, int ldb, int ldc, int relu, void* stream) {
     if (k % 32) return fail(ER_ERR_INVALID, "er_k_gemm_f16s: k must be a multiple of 32");
+    hipStream_t st = (hipStream_t)stream;
     GemmArgs g = gemm_args_default();
     g.A = a; g.B = reinterpret_cast<const float*>(w); g.C = cc; g.bias = bias; g.resid = resid; g.M = m; g.N = n; g.K = k;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.relu = relu;
-    HIPRET(launch_gemm_f16s(g, (hipStream_t)stream));
+    if (k % XBK == 0 && !(ldb & 7)) {      // the product path of the fast-mode prefill: split pass + LDS-DMA kernel (linear_hs)
+        _Float16 *hi = nullptr, *lo = nullptr;
+        HIPCHK(hipMalloc(&hi, (size_t)m * k * 2));
+        HIPCHK(hipMalloc(&lo, (size_t)m * k * 2));
+        hipLaunchKernelGGL(split_rows_f16_kernel, dim3(ew_grid((long long)m * k / 4)), dim3(ER_WG), 0, st, a, hi, lo, (long long)m, k, lda);
+        g.A = reinterpret_cast<const float*>(hi); g.a_lo = lo; g.lda = k;
+        hipError_t e = launch_gemm_hh_split(g, st);
+        hipError_t e2 = hipStreamSynchronize(st);
+        hipFree(hi); hipFree(lo);
+        HIPRET(e);
+        HIPRET(e2);
+        return ER_OK;
+    }
+    HIPRET(launch_gemm_f16s(g, st));      // k % 64 != 0: the register-staged kernel
     return ER_OK;
 }
 

@@ -47,6 +47,8 @@ struct GemmArgs {
     // (gemm_hh_mfma_kernel reads fp16 activations straight into LDS), written by the kernel that produces it
     _Float16* c16;
     int ldc16;
+    // split-activation form of the LDS-DMA kernel (fast-mode prefill): A = a_hi (through g.A) + a_lo, both fp16 [M][lda]
+    const _Float16* a_lo;
 };
 
 constexpr int GBK = 32;
@@ -565,10 +567,15 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
     }
 }
 
-template <int TM, int TN, int HEPI = HEPI_PLAIN>
+// SPLIT: the A operand is hi + lo (two fp16 arrays: a = fp16(x), lo = fp16(x - hi), |x - hi - lo| <= 2^-22 |x|), every weight fragment
+// is multiplied by both (the lo products first), i.e. the fp16-weight x fp32-activation product to fp32 round-off - what
+// gemm_f16s_mfma_kernel computes from an fp32 A with a register-staged split; same MFMA order per accumulator -> same bits.
+template <int TM, int TN, int HEPI = HEPI_PLAIN, bool SPLIT = false>
 __global__ __launch_bounds__(ER_WG) void gemm_hh_mfma_kernel(GemmArgs g, int ntx) {
-    constexpr int GBM = 64 * TM, GBN = 64 * TN, STAGE = (GBM + GBN) * XBK;     // halves per stage: A rows, then B rows
+    constexpr int GBM = 64 * TM, GBN = 64 * TN, AROWS = SPLIT ? 2 * GBM : GBM;
+    constexpr int STAGE = (AROWS + GBN) * XBK;                                   // halves per stage: A rows (hi, then lo), then B rows
     constexpr int NAI = GBM / 32, NBI = GBN / 32;                                // 8-row LDS-DMA pieces per wave and operand
+    static_assert(2 * STAGE * 2 <= 65536, "two stages fit the static LDS limit");
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * STAGE];             // the ONLY LDS object (a second one makes hipcc drain vmcnt per k-step)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -585,11 +592,14 @@ __global__ __launch_bounds__(ER_WG) void gemm_hh_mfma_kernel(GemmArgs g, int ntx
     // per-lane source pointers of this wave's LDS-DMA pieces: piece i covers tile rows 8i .. 8i+7, lane -> (row 8i + lane/8, slot lane%8)
     const int lrow = lane >> 3, lslot = lane & 7;
     const _Float16* pa[NAI];
+    const _Float16* pl[SPLIT ? NAI : 1];
     const _Float16* pb[NBI];
 #pragma unroll
     for (int j = 0; j < NAI; ++j) {
         const int r = 8 * (wid * NAI + j) + lrow;
-        pa[j] = A + (long long)min(m0 + r, g.M - 1) * g.lda + ((lslot ^ ((r >> 1) & 7)) << 3);
+        const long long off = (long long)min(m0 + r, g.M - 1) * g.lda + ((lslot ^ ((r >> 1) & 7)) << 3);
+        pa[j] = A + off;
+        if (SPLIT) pl[j] = g.a_lo + off;
     }
 #pragma unroll
     for (int j = 0; j < NBI; ++j) {
@@ -598,10 +608,15 @@ __global__ __launch_bounds__(ER_WG) void gemm_hh_mfma_kernel(GemmArgs g, int ntx
     }
     auto issue = [&](int kt, int s) {
         _Float16* as = lds + s * STAGE;
-        _Float16* bs = as + GBM * XBK;
+        _Float16* bs = as + AROWS * XBK;
 #pragma unroll
         for (int j = 0; j < NAI; ++j)
             __builtin_amdgcn_global_load_lds((er_gptr)(pa[j] + kt * XBK), (er_lptr)(as + 8 * (wid * NAI + j) * XBK), 16, 0, 0);
+        if (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < NAI; ++j)
+                __builtin_amdgcn_global_load_lds((er_gptr)(pl[j] + kt * XBK), (er_lptr)(as + (GBM + 8 * (wid * NAI + j)) * XBK), 16, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < NBI; ++j)
             __builtin_amdgcn_global_load_lds((er_gptr)(pb[j] + kt * XBK), (er_lptr)(bs + 8 * (wid * NBI + j) * XBK), 16, 0, 0);
@@ -623,15 +638,23 @@ __global__ __launch_bounds__(ER_WG) void gemm_hh_mfma_kernel(GemmArgs g, int ntx
         const int cur = kt & 1;
         if (kt + 1 < nk) issue(kt + 1, cur ^ 1);      // lands while this tile is multiplied
         const _Float16* as = lds + cur * STAGE + (wm * 32 * TM + li) * XBK;
-        const _Float16* bs = lds + cur * STAGE + GBM * XBK + (wn * 32 * TN + li) * XBK;
+        const _Float16* bs = lds + cur * STAGE + AROWS * XBK + (wn * 32 * TN + li) * XBK;
 #pragma unroll
         for (int ks = 0; ks < XBK / 16; ++ks) {
             const int co = ((2 * ks + kh) ^ swz) << 3;
             h16x8 av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const h16x8*>(as + 32 * i * XBK + co);
-#pragma unroll
             for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const h16x8*>(bs + 32 * j * XBK + co);
+            if (SPLIT) {      // the small (lo) products first, then the large ones: the accumulator sees them in increasing magnitude
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const h16x8*>(as + (GBM + 32 * i) * XBK + co);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const h16x8*>(as + 32 * i * XBK + co);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -642,6 +665,7 @@ __global__ __launch_bounds__(ER_WG) void gemm_hh_mfma_kernel(GemmArgs g, int ntx
     }
     // every wave is past the last barrier: the stage buffers are free.  Wave w's (32 TM) x (32 TN) floats fit its quarter of them
     static_assert(4 * 32 * TM * 32 * TN * 4 <= 2 * STAGE * 2, "epilogue staging fits the stage buffers");
+    static_assert(!SPLIT || TM == 1, "split form: 64-row tiles (two A images per stage)");
     float* sw = reinterpret_cast<float*>(lds) + wid * (32 * TM * 32 * TN);
     gemm_hh_epilogue<TM, TN, HEPI>(g, sw, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
 }
@@ -722,6 +746,35 @@ inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st, int force_ti
     if (tile == 1) hipLaunchKernelGGL((gemm_hh_mfma_kernel<2, 2>), grid, dim3(ER_WG), 0, st, g, ntx);
     else if (tile == 2) hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 2>), grid, dim3(ER_WG), 0, st, g, ntx);
     else hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 1>), grid, dim3(ER_WG), 0, st, g, ntx);
+    return hipGetLastError();
+}
+
+// x (fp32 rows) -> hi = fp16(x), lo = fp16(x - hi): the two A operands of the split form (exactly the split the register-staged
+// gemm_f16s_mfma_kernel performs on its way into LDS)
+__global__ __launch_bounds__(ER_WG) void split_rows_f16_kernel(const float* x, _Float16* hi, _Float16* lo, long long rows, int cols, int ldx) {
+    const long long total = rows * (cols / 4);
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
+        const long long r = i / (cols / 4);
+        const int c = (int)(i - r * (cols / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+        const h16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        const h16x4 l = {(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+        *reinterpret_cast<h16x4*>(hi + r * cols + c) = h;
+        *reinterpret_cast<h16x4*>(lo + r * cols + c) = l;
+    }
+}
+
+// split form: A = a_hi (g.A) + a_lo (g.a_lo), fp16 [M][lda]; 64-row tiles
+inline hipError_t launch_gemm_hh_split(const GemmArgs& g, hipStream_t st) {
+    if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7) || !g.a_lo) return hipErrorInvalidValue;
+    const long long w2 = (long long)((g.M + 63) / 64) * ((g.N + 127) / 128);
+    if (w2 >= 256) {
+        const int ntx = (g.N + 127) / 128;
+        hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 2, HEPI_PLAIN, true>), dim3(ntx * ((g.M + 63) / 64)), dim3(ER_WG), 0, st, g, ntx);
+    } else {
+        const int ntx = (g.N + 63) / 64;
+        hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 1, HEPI_PLAIN, true>), dim3(ntx * ((g.M + 63) / 64)), dim3(ER_WG), 0, st, g, ntx);
+    }
     return hipGetLastError();
 }
 
