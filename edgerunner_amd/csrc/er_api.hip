@@ -119,9 +119,8 @@ struct er_ctx {
     // shapes are fixed (out_proj 3 waves x 1 row, fc2 4 K-slices x 2 rows, 128-key chunks for the fixed-chunk attention): their
     // round-1/2 knobs (ER_RW_*, ER_NW_OUT, ER_ATTN_STEPS, ER_ATTN_V, ER_COMBINE_V, ER_ATTN_GRID_HS, ER_OUT_VALU) are settled and gone
     int nw_qkv = 6, nw_fc1 = 4;
-    int prefill_attn_f16s = -1;   // fast-mode prefix attention on the fp16 matrix cores with hi/lo-split q and p: -1 = auto (batches of >= 2
-                                  // prefixes: 13-14 % off encode + prefill at B = 8 / 32, 3 % slower at B = 1, profiles/r03_f16s_prefix_attention.log),
-                                  // ER_PREFILL_ATTN_F16S=0 / 1 = never / always (parity matrix)
+    int prefill_attn_f16s = -1;   // fast-mode prefix attention on the fp16 matrix cores with hi/lo-split q and p (k_flash_attn_f16s.h): on unless
+                                  // ER_PREFILL_ATTN_F16S=0 (the fp32-matrix-core kernel; kept for the parity matrix)
     int prof_len = 0;         // > 0: attention kernels run at this fixed length (er_profile_decode_kernels_at)
     int attn_v_batched = 0;   // attention kernel at B > 4 (env ER_ATTN_V_BATCHED): 0 = auto (streaming when B*H >= 256, else split + merge), 1 = split kernel + merge, 3 = one streaming workgroup per (row, head), no merge
     bool stream_attn = false; // batched, D == 96 and (forced or B*H >= 256: at least one streaming workgroup per CU)
@@ -1143,7 +1142,7 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
                 f.V = qkv + 2 * H; f.ldv = 3 * H; f.vs_b = f.qs_b; f.vs_h = D;
                 f.O = a; f.ldo = H; f.os_b = (long long)S * H; f.os_h = D;
                 f.N = S; f.M = S; f.sqrt_d = sqrtf((float)D); f.causal_off = 0;
-                const bool f16s = D == 96 && (c->prefill_attn_f16s == 1 || (c->prefill_attn_f16s < 0 && B >= 2));
+                const bool f16s = D == 96 && c->prefill_attn_f16s != 0;
                 if (f16s) HIPRET(launch_flash_attn_f16s(f, D, true, NH, B, st));   // K / V in the scratch are fp16 values already
                 else HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
             }
@@ -1575,6 +1574,27 @@ extern "C" int er_k_gemm_hh(const float* a, const void* w, const float* bias, co
     g.M = m; g.N = n; g.K = k; g.lda = k; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.relu = relu;
     g.c16 = reinterpret_cast<_Float16*>(c16_out); g.ldc16 = n;
     hipError_t e = launch_gemm_hh(g, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(a16);
+    HIPRET(e);
+    HIPRET(e2);
+    return ER_OK;
+}
+
+extern "C" int er_k_gemm_hh_qkv(const float* a, const void* w, const float* bias, void* qk16_out, void* vt_out, int m, int n, int k,
+                                int rows_per_batch, int force_tile, void* stream) {
+    if (k % 64 || n % 192 || m % 64 || rows_per_batch <= 0 || rows_per_batch % 64 || m % rows_per_batch)
+        return fail(ER_ERR_INVALID, "er_k_gemm_hh_qkv: k, m, rows_per_batch multiples of 64, n of 192");
+    hipStream_t st = (hipStream_t)stream;
+    _Float16* a16 = nullptr;
+    HIPCHK(hipMalloc(&a16, (size_t)m * k * sizeof(_Float16)));
+    hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)m * k)), dim3(ER_WG), 0, st, a, a16, (long long)m, k, k, k);
+    GemmArgs g = gemm_args_default();
+    g.A = reinterpret_cast<const float*>(a16); g.B = reinterpret_cast<const float*>(w); g.bias = bias;
+    g.M = m; g.N = n; g.K = k; g.lda = k; g.ldb = k; g.ldc = n; g.ldr = n;
+    g.c16 = reinterpret_cast<_Float16*>(qk16_out); g.ldc16 = n;
+    g.vt16 = reinterpret_cast<_Float16*>(vt_out); g.vt_col0 = 2 * (n / 3); g.vt_rows = rows_per_batch; g.vt_ld = rows_per_batch;
+    hipError_t e = launch_gemm_hh(g, st, force_tile);
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(a16);
     HIPRET(e);

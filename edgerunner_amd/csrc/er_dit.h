@@ -304,13 +304,16 @@ static int dit_build_geglu_perm(er_dit_ctx* c, hipStream_t st) {
 }
 
 // fp16 mode, A already in fp16 (written by its producer): both operands by LDS-DMA.  c16: optional fp16 copy of the output.
+// vt16 / vt_rows: the V third of a fused q/k/v projection leaves as V^T per head (GemmArgs::vt16), vt_rows tokens per batch entry.
 static hipError_t dlin16(er_dit_ctx* c, const _Float16* A16, int lda, const float* W, const float* bias, float* C, int ldc, int M,
-                         int N, int K, const float* resid, int ldr, const float* gate, int gate_rows, _Float16* c16, hipStream_t st) {
+                         int N, int K, const float* resid, int ldr, const float* gate, int gate_rows, _Float16* c16, hipStream_t st,
+                         _Float16* vt16 = nullptr, int vt_rows = 0) {
     GemmArgs g = gemm_args_default();
     g.A = reinterpret_cast<const float*>(A16); g.C = C; g.bias = bias; g.resid = resid; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldr;
     g.gate = gate; g.gate_rows = gate_rows; g.gate_bstride = N;
     g.c16 = c16; g.ldc16 = N;
+    if (vt16) { g.vt16 = vt16; g.vt_col0 = 2 * (N / 3); g.vt_rows = vt_rows; g.vt_ld = vt_rows; }
     auto it = c->half_of.find(W);
     if (it == c->half_of.end()) return hipErrorInvalidValue;
     g.B = reinterpret_cast<const float*>(it->second);
@@ -433,10 +436,8 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         // x = norm1(x) * (1 + scale_msa) + shift_msa   (chunks 0 = shift, 1 = scale, 2 = gate)     dit.py:129-132
         HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st, x16));
         // x = x + gate_msa * attn1(x)                                               dit.py:133
-        if (hh) {     // q, k, v leave the GEMM in fp16 only; V is transposed per head; K and V^T tiles then reach LDS by DMA
-            HIPRET(dlin16(c, x16, C, L.qkv_w, L.qkv_b, nullptr, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, qkv16, st));
-            hipLaunchKernelGGL(transpose_v_f16_kernel, dim3(N / 64, H, B), dim3(ER_WG), 0, st, qkv16 + 2 * C, vt16, N, N, 3 * C, (long long)N * 3 * C);
-            HIPRET(hipGetLastError());
+        if (hh) {     // q, k leave the GEMM in fp16 only and V as V^T per head (its epilogue); K and V^T tiles then reach LDS by DMA
+            HIPRET(dlin16(c, x16, C, L.qkv_w, L.qkv_b, nullptr, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, qkv16, st, vt16, N));
             FlashHArgs fh{};
             fh.Q = qkv16; fh.K = qkv16 + C; fh.Vt = vt16; fh.O16 = att16; fh.N = N; fh.M = N;
             fh.ldq = fh.ldk = 3 * C; fh.ldvt = N; fh.ldo = C;

@@ -1,6 +1,7 @@
-// The fast-mode prefill attention on the fp16 matrix cores with fp32-grade operands: the default for batches of >= 2
-// prefixes (round 3: encode + prefill per sample 15.5 -> 13.4 ms at B = 8, 14.65 -> 12.65 ms at B = 32; at B = 1 it is 3 % slower
-// than the fp32 kernel and not used; end-to-end fast-mode logits move by 2.9e-6, profiles/r03_f16s_prefix_attention.log).
+// The fast-mode prefill attention on the fp16 matrix cores with fp32-grade operands: the default for every batch size (round 3,
+// encode + prefill per sample against the fp32-matrix-core kernel: 21.9 -> 19.3 ms at B = 1, 15.5 -> 12.8 ms at B = 8, 14.65 -> 12.2 ms
+// at B = 32; end-to-end fast-mode logits move by 2.9e-6; profiles/r03_f16s_prefix_attention.log,
+// profiles/r03_dit_vt_epilogue_prefill_prefetch.log).
 //
 // In fast mode the K / V rows the prefix attention reads are already fp16 values (kv_scatter_half_kernel rounds them to
 // the cache dtype, er_api.hip), but the fused attention still runs on the fp32 matrix cores (flash_attn_f32_kernel: 7.4 of
@@ -25,6 +26,10 @@ constexpr float FAS_QSCALE = 16.0f, FAS_PSCALE = 1024.0f;
 
 // grid (ceil(N / (32 NWV)), H, B), 64 NWV threads; arguments as flash_attn_f32_kernel (Flash32Args), K / V must hold
 // fp16-representable values (they are converted, not rounded, on their way into LDS).
+// The K / V rows of tile t + 1 are loaded into registers while tile t is multiplied (96 more registers at NWV = 2).  The kernel holds
+// more than 256 registers either way (q hi / lo 48, O^T 48, S^T 32, one tile's staging set: one wave per SIMD), so nothing but this
+// prefetch hides the load -> convert -> LDS latency of a tile: ONE 2050-token prefix is 33 x 16 = 528 two-wave workgroups whose longest
+// walks 33 tiles (without it: 22.6 instead of 19.3 ms of encode + prefill at B = 1, 12.98 instead of 12.79 ms per sample at B = 8).
 template <int D, bool CAUSAL, int NWV>
 __global__ __launch_bounds__(64 * NWV) void flash_attn_f16s_kernel(Flash32Args a) {
     constexpr int THREADS = 64 * NWV;
@@ -77,25 +82,34 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f16s_kernel(Flash32Args a
 
     constexpr int NST = (KT * F4) / THREADS;
     static_assert((KT * F4) % THREADS == 0, "staging loop shape");
+    f32x4 kpre[NST], vpre[NST];
+    auto fetch = [&](int kbase, int u, f32x4& kv, f32x4& vv) {
+        const int idx = tid + THREADS * u, key = idx / F4, c4 = idx - key * F4;
+        const int gk = min(kbase + key, a.M - 1);
+        kv = *reinterpret_cast<const f32x4*>(K + (long long)gk * a.ldk + 4 * c4);
+        vv = *reinterpret_cast<const f32x4*>(V + (long long)gk * a.ldv + 4 * c4);
+    };
+    auto stage = [&](int u, const f32x4& kv, const f32x4& vv) {
+        const int idx = tid + THREADS * u, key = idx / F4, c4 = idx - key * F4;
+        *reinterpret_cast<fa_h4*>(&Ks[key * KLD + 4 * c4]) = (fa_h4){(_Float16)kv.x, (_Float16)kv.y, (_Float16)kv.z, (_Float16)kv.w};
+        Vt[(4 * c4 + 0) * VLD + key] = (_Float16)vv.x;
+        Vt[(4 * c4 + 1) * VLD + key] = (_Float16)vv.y;
+        Vt[(4 * c4 + 2) * VLD + key] = (_Float16)vv.z;
+        Vt[(4 * c4 + 3) * VLD + key] = (_Float16)vv.w;
+    };
+#pragma unroll
+    for (int u = 0; u < NST; ++u) fetch(0, u, kpre[u], vpre[u]);
     for (int t = 0; t < ntiles; ++t) {
         const int kbase = t * KT;
         __syncthreads();                     // previous tile fully consumed
-        // stage K -> Ks[key][d], V -> Vt[d][key] as fp16 (exact: the values are fp16 already).  No register prefetch of the
-        // next tile: with q hi/lo (48), O^T (48) and S^T (32 registers) resident, a prefetch set pushed the kernel to one wave
-        // per SIMD; two to three resident workgroups per CU hide the staging latency instead.
+        // stage K -> Ks[key][d], V -> Vt[d][key] as fp16 (exact: the values are fp16 already)
 #pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int idx = tid + THREADS * u, key = idx / F4, c4 = idx - key * F4;
-            const int gk = min(kbase + key, a.M - 1);
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(K + (long long)gk * a.ldk + 4 * c4);
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(V + (long long)gk * a.ldv + 4 * c4);
-            *reinterpret_cast<fa_h4*>(&Ks[key * KLD + 4 * c4]) = (fa_h4){(_Float16)kv.x, (_Float16)kv.y, (_Float16)kv.z, (_Float16)kv.w};
-            Vt[(4 * c4 + 0) * VLD + key] = (_Float16)vv.x;
-            Vt[(4 * c4 + 1) * VLD + key] = (_Float16)vv.y;
-            Vt[(4 * c4 + 2) * VLD + key] = (_Float16)vv.z;
-            Vt[(4 * c4 + 3) * VLD + key] = (_Float16)vv.w;
-        }
+        for (int u = 0; u < NST; ++u) stage(u, kpre[u], vpre[u]);
         __syncthreads();
+        if (t + 1 < ntiles) {
+#pragma unroll
+            for (int u = 0; u < NST; ++u) fetch(kbase + KT, u, kpre[u], vpre[u]);
+        }
         if (kbase > wave_last_key) continue;   // wave-uniform: the barriers above are still hit by every wave
 
         // S^T = K Q^T: two 32-key blocks; lane (li, half) holds keys kbase + kb*32 + (r&3) + 8*(r>>2) + 4*half

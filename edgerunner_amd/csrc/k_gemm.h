@@ -49,6 +49,11 @@ struct GemmArgs {
     int ldc16;
     // split-activation form of the LDS-DMA kernel (fast-mode prefill): A = a_hi (through g.A) + a_lo, both fp16 [M][lda]
     const _Float16* a_lo;
+    // LDS-DMA kernel, optional: columns >= vt_col0 (the V third of a fused q/k/v projection, 64 columns per head) are NOT written to
+    // c16 but TRANSPOSED per head into vt16 [M / vt_rows][heads][64][vt_ld], keys in fa_vt_pos order - the V^T operand of
+    // flash_attn_hh_kernel, written by the GEMM that produces V instead of a transpose pass over it.  M % 64 == 0, vt_rows % 64 == 0.
+    _Float16* vt16;
+    int vt_col0, vt_rows, vt_ld;
 };
 
 constexpr int GBK = 32;
@@ -502,6 +507,31 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
             for (int r = 0; r < 16; ++r) sw[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh) * WC + 32 * j + li] = acc[i][j][r];
     // (same wave writes and reads: the LDS queue is in order, no barrier)
     if constexpr (HEPI == HEPI_PLAIN) {
+        if (g.vt16 && nw >= g.vt_col0) {      // wave-uniform: the V columns of this wave's block go out as V^T rows
+            // lane -> (column d of the block, a run of WR / LPD keys): 16 keys per step = two 16-byte chunks of the V^T row in
+            // fa_vt_pos order ({0-3, 8-11}, {4-7, 12-15}); the column walk down the LDS rows is conflict-free up to the two lanes
+            // that share a bank when the block is 64 columns wide
+            constexpr int LPD = 64 / WC, KPL = WR / LPD;
+            static_assert(KPL % 16 == 0, "whole 16-key groups per lane");
+            const int d = lane % WC, kk0 = (lane / WC) * KPL;
+            const int col = nw - g.vt_col0 + d, hh = col >> 6, dd = col & 63;
+            const int heads = (g.N - g.vt_col0) >> 6;
+            const float bias = g.bias ? g.bias[nw + d] : 0.f;
+            const int gm0 = mw + kk0, b = gm0 / g.vt_rows, key0 = gm0 - b * g.vt_rows;      // KPL | 64 | vt_rows: the run stays in one batch
+            if (gm0 >= g.M) return;
+            _Float16* dst = g.vt16 + (((long long)b * heads + hh) * 64 + dd) * g.vt_ld + key0;
+#pragma unroll
+            for (int q = 0; q < KPL / 16; ++q) {
+                float e[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) e[t] = sw[(kk0 + 16 * q + t) * WC + d] + bias;
+                const h16x8 c0 = {(_Float16)e[0], (_Float16)e[1], (_Float16)e[2], (_Float16)e[3], (_Float16)e[8], (_Float16)e[9], (_Float16)e[10], (_Float16)e[11]};
+                const h16x8 c1 = {(_Float16)e[4], (_Float16)e[5], (_Float16)e[6], (_Float16)e[7], (_Float16)e[12], (_Float16)e[13], (_Float16)e[14], (_Float16)e[15]};
+                *reinterpret_cast<h16x8*>(dst + 16 * q) = c0;
+                *reinterpret_cast<h16x8*>(dst + 16 * q + 8) = c1;
+            }
+            return;
+        }
         constexpr int LPR = WC / 4, RPP = 64 / LPR;              // lanes per row, rows per pass
         const int c4 = lane % LPR, rr0 = lane / LPR;
         const int gn = nw + 4 * c4;
@@ -739,6 +769,9 @@ inline int gemm_hh_pick_tile(int M, int N) {
 // A = fp16 [M][lda], B = fp16 weights [N][ldb] (both through g.A / g.B), K % 64 == 0
 inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st, int force_tile = 0) {
     if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7)) return hipErrorInvalidValue;
+    if (g.vt16 && ((g.M & 63) || (g.vt_rows & 63) || (g.vt_col0 & 127) || ((g.N - g.vt_col0) & 63) || (g.vt_ld & 7) || g.div != 0.f || g.relu ||
+                   g.gate || g.resid))
+        return hipErrorInvalidValue;
     const int tile = force_tile ? force_tile : gemm_hh_pick_tile(g.M, g.N);
     const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
     const int ntx = (g.N + bn - 1) / bn, nty = (g.M + bm - 1) / bm;

@@ -90,6 +90,20 @@ def gemm_hh(a, w_half, bias=None, resid=None, relu=False, return_half=False):
     return (c, c16) if return_half else c
 
 
+def gemm_hh_qkv(a, w_half, bias, rows_per_batch, force_tile=0):
+    """Fused q/k/v projection through the LDS-DMA kernel: returns (qk16 [M, N] whose V third is left as allocated, V^T
+    [M / rows_per_batch, heads, 64, rows_per_batch] in the key order of flash_attn_hh_kernel)."""
+    lib = native.load_library()
+    M, K = a.shape
+    N = w_half.shape[0]
+    heads = N // 192
+    qk16 = torch.zeros((M, N), dtype=torch.float16, device=a.device)
+    vt = torch.zeros((M // rows_per_batch, heads, 64, rows_per_batch), dtype=torch.float16, device=a.device)
+    native.check(lib.er_k_gemm_hh_qkv(native.ptr(a.contiguous()), native.ptr(w_half.contiguous()), native.ptr(bias), native.ptr(qk16), native.ptr(vt),
+                                      M, N, K, rows_per_batch, force_tile, _st()), "er_k_gemm_hh_qkv")
+    return qk16, vt
+
+
 def gemm_f16s(a, w_half, bias=None, resid=None, relu=False):
     """C = relu?(fp16(A) . W^T + bias) (+resid) on the fp16-input MFMA path; a fp32 [M,K], w_half fp16 [N,K]."""
     lib = native.load_library()

@@ -278,6 +278,14 @@ int er_k_gemm_f16(const float* a_dev, const void* w_half_dev, const float* bias_
  * DiT path the producing kernel writes that copy); c16_out_dev (optional) receives the result rounded to fp16 [m][n] */
 int er_k_gemm_hh(const float* a_dev, const void* w_half_dev, const float* bias_dev, const float* resid_dev, float* c_dev,
                  void* c16_out_dev, int m, int n, int k, int lda, int ldb, int ldc, int relu, void* stream);
+/* the fused q/k/v projection of the DiT self-attention (core/transformer/dit.py:100-126 -> attention.py:176-178) as the LDS-DMA
+ * kernel runs it: n = 3 * heads * 64 output columns, the first two thirds (q, k) rounded to fp16 into qk16_out_dev [m][n] (its V
+ * columns are left untouched), the V third written by the GEMM epilogue as V^T per head into vt_out_dev
+ * [m / rows_per_batch][heads][64][rows_per_batch], keys in the order flash_attn_hh_kernel reads them (position of key k inside its
+ * group of 16: {0-3, 8-11, 4-7, 12-15}).  m, rows_per_batch multiples of 64; force_tile 0 = the product rule, 1 / 2 / 3 = 128x128 /
+ * 64x128 / 64x64 tiles. */
+int er_k_gemm_hh_qkv(const float* a_dev, const void* w_half_dev, const float* bias_dev, void* qk16_out_dev, void* vt_out_dev, int m,
+                     int n, int k, int rows_per_batch, int force_tile, void* stream);
 int er_k_gemm_f16s(const float* a, const void* w_half, const float* bias, const float* resid, float* c, int m, int n, int k,
                    int lda, int ldb, int ldc, int relu, void* stream);
 /* softmax(q k^T / 8) v, head_dim 64, non-causal, fp16 operands / fp32 accumulate; q,o [B,N,H*64], k,v [B,M,H*64] fp32 */
@@ -288,13 +296,12 @@ int er_k_flash_attn_f16(const float* q_dev, const float* k_dev, const float* v_d
  * head_dim 96, and for the point encoder's cross-attention, head_dim 64).  q/o: [B, N, H*D], k/v: [B, M, H*D]. */
 int er_k_flash_attn_f32(const float* q, const float* k, const float* v, float* o, int batch, int heads, int n, int m,
                         int head_dim, int causal, void* stream);
-/* STAGED for round 3 (unmeasured, not on the default path; env ER_PREFILL_ATTN_F16S=1 selects it for the fast-mode prefill):
- * the same attention for head_dim 96 on the fp16 matrix cores with hi/lo-split q and p; k / v must hold
- * fp16-representable values (the fast-mode prefill's scratch does) */
 /* the same attention with q / k / v in fp16 brought in by LDS-DMA (V transposed per head): the unit entry converts and transposes
  * the fp32 inputs first and widens the fp16 output */
 int er_k_flash_attn_hh(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch, int heads, int n, int m,
                        void* stream);
+/* the attention of er_k_flash_attn_f32 for head_dim 96 on the fp16 matrix cores with hi/lo-split q and p (the fast-mode prefill's
+ * prefix attention, csrc/k_flash_attn_f16s.h); k / v must hold fp16-representable values (the fast-mode prefill's scratch does) */
 int er_k_flash_attn_f16s(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int batch, int heads,
                          int n_queries, int m_keys, int causal, void* stream);
 int er_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,

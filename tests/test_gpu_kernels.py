@@ -327,6 +327,28 @@ def test_gemm_hh_lds_dma(M, N, K):
         assert torch.equal(K_.gemm_hh(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,rows,heads,K", [(4096, 2048, 16, 1024), (256, 64, 2, 64), (384, 128, 4, 192)])
+def test_gemm_hh_qkv_writes_v_transposed(M, rows, heads, K, tile):
+    """The q/k/v projection of the DiT self-attention (core/transformer/dit.py:100-126): q and k leave the GEMM as fp16 rows, V as
+    V^T per head in the key order flash_attn_hh_kernel reads (replaces a separate transpose pass): every element must be BIT-EQUAL
+    to the plain epilogue's fp16 copy, for all tile shapes, and the V columns of the row output must stay untouched."""
+    from edgerunner_amd import kernels as K_
+    N = 3 * heads * 64
+    a, w, bias = rnd(M, K, seed=91), rnd(N, K, seed=92, scale=0.05), rnd(N, seed=93)
+    wh = w.half()
+    _, c16 = K_.gemm_hh(a, wh, bias, None, return_half=True)
+    qk16, vt = K_.gemm_hh_qkv(a, wh, bias, rows, force_tile=tile)
+    assert torch.equal(qk16[:, :2 * N // 3], c16[:, :2 * N // 3]), "q / k rows"
+    assert float(qk16[:, 2 * N // 3:].abs().max()) == 0.0, "the V third of the row output must not be written"
+    v = c16[:, 2 * N // 3:].view(M // rows, rows, heads, 64).permute(0, 2, 3, 1)         # [b][h][d][key]
+    key = torch.arange(rows, device=DEV)
+    pos = (key & ~15) | (key & 3) | ((key & 8) >> 1) | ((key & 4) << 1)                   # fa_vt_pos
+    want = torch.empty_like(vt)
+    want[..., pos] = v
+    assert torch.equal(vt, want), "V^T per head in MFMA key order"
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (2050, 4608, 1536), (2050, 1536, 6144), (514, 3072, 1024), (77, 200, 608)])
 def test_gemm_f16_split_activations(M, N, K):
     """Split-fp16 GEMM (fast-mode prefill): fp16 weights x (hi + lo)-split fp32 activations must equal the fp32-activation

@@ -419,12 +419,13 @@ def test_fast_mode_vs_storage_rounding_emulation(gold_small):
 
 
 def test_fast_mode_with_split_fp16_prefix_attention(monkeypatch):
-    """ER_PREFILL_ATTN_F16S=1 (prefix attention on the fp16 matrix cores, hi/lo-split q and p): the fast-mode model must stay
-    the model the default fp32-matrix-core attention computes - same greedy ids, prefill logits to fp32 round-off."""
+    """The fast-mode prefix attention runs on the fp16 matrix cores with hi/lo-split q and p (k_flash_attn_f16s.h); with
+    ER_PREFILL_ATTN_F16S=0 it runs on the fp32 matrix cores.  Both must be the same model: same greedy ids, prefill logits to
+    fp32 round-off."""
     base = make_lmm(precision="fp16")
     _, t0 = base.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
     l0 = teacher_forced_logits(base, cloud(2), 1000, t0[0], {0, 1, 31})
-    monkeypatch.setenv("ER_PREFILL_ATTN_F16S", "1")
+    monkeypatch.setenv("ER_PREFILL_ATTN_F16S", "0")
     key = ("f16s",)                                        # a separate context: the knob is read at er_create
     from edgerunner_amd import weights as W
     from edgerunner_amd.models import LMM
@@ -433,7 +434,7 @@ def test_fast_mode_with_split_fp16_prefix_attention(monkeypatch):
     m = LMM(opt, DEV, precision="fp16")
     m.mesh_decoder.load_state_iter(W.iter_state_dict(opt, 0, "perturbed"), strict=True)
     _, t1 = m.generate(cloud(2), 1000, tokenizer=object(), max_new_tokens=64, min_new_tokens=64)
-    assert_ids(t1[0], t0[0], "fast mode, split-fp16 prefix attention vs the fp32 one")
+    assert_ids(t1[0], t0[0], "fast mode, fp32 prefix attention vs the split-fp16 one")
     l1 = teacher_forced_logits(m, cloud(2), 1000, t0[0], {0, 1, 31})
     err = max(np.abs(l1[t] - l0[t]).max() for t in l0)
     print(f"split-fp16 prefix attention vs fp32 prefix attention, max|dlogit|: {err:.3e}")
