@@ -133,8 +133,7 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_kernel(AttnDecArgs a) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
         }
-#pragma unroll
-        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        acc = lane_group_sum<LPK>(acc);
         sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
         mloc = fmaxf(mloc, sc[i]);
     }
@@ -170,8 +169,7 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_kernel(AttnDecArgs a) {
     for (int j = 0; j < NV; ++j)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-#pragma unroll
-            for (int off = LPK; off < 64; off <<= 1) o[j][e] += __shfl_xor(o[j][e], off, 64);
+            o[j][e] = across_groups_sum<LPK>(o[j][e]);
         }
     if (g == 0) {
 #pragma unroll
@@ -253,8 +251,7 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
         }
-#pragma unroll
-        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        acc = lane_group_sum<LPK>(acc);
         sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
         mloc = fmaxf(mloc, sc[i]);
     }
@@ -437,8 +434,7 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
         }
-#pragma unroll
-        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        acc = lane_group_sum<LPK>(acc);
         sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
         mloc = fmaxf(mloc, sc[i]);
     }
@@ -620,8 +616,7 @@ __device__ __forceinline__ void attn_stream_reduce(const AttnTile<KT, D, STEPS>&
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
         }
-#pragma unroll
-        for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        acc = lane_group_sum<LPK>(acc);
         const bool valid = kbase + (i * ER_NWAVES + wid) * KPW + g < len;
         sc[i] = valid ? acc / sqrt_d : -INFINITY;
         mloc = fmaxf(mloc, sc[i]);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f16_kernel(FlashArgs a) {
                     mloc = fmaxf(mloc, s);
                 }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = xor_max<32>(mloc);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // m_run = -inf on the first tile -> 0
         float psum = 0.f;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f16_kernel(FlashArgs a) {
                 }
             }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xor_sum<32>(l_run);
     const int q = q0 + li;
     if (q < a.N) {
 #pragma unroll
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
                     mloc = fmaxf(mloc, s);
                 }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = xor_max<32>(mloc);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
                 }
             }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xor_sum<32>(l_run);
     const int q = q0 + li;
     if (q < a.N) {
 #pragma unroll

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f16s_kernel(Flash32Args a
                 st[kb][r] = s;
                 mloc = fmaxf(mloc, s);
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = xor_max<32>(mloc);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = (m_new == -INFINITY) ? 1.0f : expf(m_run - m_new);   // m_run = -inf -> exp(-inf) = 0
         float psum = 0.f;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f16s_kernel(Flash32Args a
                 }
             }
     }
-    const float l_tot = (l_run + __shfl_xor(l_run, 32, 64)) * FAS_PSCALE;
+    const float l_tot = (xor_sum<32>(l_run)) * FAS_PSCALE;
     if (qi < a.N) {
         float* orow = O + (long long)qi * a.ldo;
 #pragma unroll

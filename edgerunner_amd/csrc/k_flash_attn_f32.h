@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
                 st[kb][r] = s;
                 mloc = fmaxf(mloc, s);
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = xor_max<32>(mloc);
         const float m_new = fmaxf(m_run, mloc);
         // m_new stays -inf only for a query that has not seen any key yet (padding rows q >= N of a causal tile)
         const float alpha = (m_new == -INFINITY) ? 1.0f : expf(m_run - m_new);   // m_run = -inf -> exp(-inf) = 0
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
                     ot[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[db * 32], st[kb][r], ot[db], 0, 0, 0);
             }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xor_sum<32>(l_run);
     if (qi < a.N) {
         float* orow = O + (long long)qi * a.ldo;
 #pragma unroll

@@ -298,7 +298,7 @@ inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t st) {
 // owns RW weight rows, keeps RW*NB accumulators and re-reads the inputs from LDS (ds_read_b128,
 // conflict-free) instead of holding them in registers.  Arithmetic per (row, batch-row) is kept
 // IDENTICAL to the B <= 4 kernel - same per-lane fmaf chain over the 1536-slice, same xor-32..1
-// reduction tree (done as a reduce-scatter so NB sums cost 17 shuffles instead of 6*NB), same
+// reduction tree (done as a reduce-scatter so NB sums cost 17 lane exchanges instead of 6*NB), same
 // slice order for K = 6144 - so a row of a batch is bit-identical to the same row run alone.
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
 
@@ -317,12 +317,12 @@ __device__ __forceinline__ float reduce_scatter(AccRow<NB> a, int lane) {   // b
             if (i < h) {
                 const float send = up ? v[i] : v[i + h];
                 const float keep = up ? v[i + h] : v[i];
-                v[i] = keep + __shfl_xor(send, m, 64);
+                v[i] = keep + lane_xor_pow2(send, m, lane);
             }
     }
     float r = v[0];
 #pragma unroll
-    for (int k = STEPS; k < 6; ++k) r += __shfl_xor(r, 32 >> k, 64);
+    for (int k = STEPS; k < 6; ++k) r += lane_xor_pow2(r, 32 >> k, lane);
     return r;
 }
 

@@ -119,12 +119,13 @@ __global__ __launch_bounds__(ER_WG) void sample_head_kernel(const float* logits,
         const float v = sc[i];
         if (v > bv) { bv = v; bi = i; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    auto take = [&](float ov, int oi) { if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } };
+    take(lane_xor_any<32>(bv, lane), (int)lane_xor_bits<32>((unsigned)bi, lane));
+    take(lane_xor_any<16>(bv, lane), (int)lane_xor_bits<16>((unsigned)bi, lane));
+    take(lane_xor_any<8>(bv, lane), (int)lane_xor_bits<8>((unsigned)bi, lane));
+    take(lane_xor_any<4>(bv, lane), (int)lane_xor_bits<4>((unsigned)bi, lane));
+    take(lane_xor_any<2>(bv, lane), (int)lane_xor_bits<2>((unsigned)bi, lane));
+    take(lane_xor_any<1>(bv, lane), (int)lane_xor_bits<1>((unsigned)bi, lane));
     if (lane == 0) { red[wid] = bv; redi[wid] = bi; }
     __syncthreads();
     float gmax = red[0];

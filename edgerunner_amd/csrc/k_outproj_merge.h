@@ -63,12 +63,10 @@ __global__ __launch_bounds__(OM_THREADS) void outproj_merge_kernel(OutMergeArgs 
     // ---- merge of this half-wave's head
     const bool act = li < NCH;
     float m = act ? ml.x : -INFINITY;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));          // stays inside the 32-lane half
+    m = xor_max<16>(m); m = xor_max<8>(m); m = xor_max<4>(m); m = xor_max<2>(m); m = xor_max<1>(m);     // stays inside the 32-lane half
     const float wgt = (act && ml.x != -INFINITY) ? expf(ml.x - m) : 0.f;           // m is finite: chunk 0 always holds a key
     float l = act ? ml.y * wgt : 0.f;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    l = xor_sum<16>(l); l = xor_sum<8>(l); l = xor_sum<4>(l); l = xor_sum<2>(l); l = xor_sum<1>(l);
     f32x4 oe = {0.f, 0.f, 0.f, 0.f}, oo = {0.f, 0.f, 0.f, 0.f};                    // even / odd partials: two independent chains
 #pragma unroll
     for (int s = 0; s < NCH; s += 2) {
