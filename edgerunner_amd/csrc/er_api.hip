@@ -693,6 +693,21 @@ static hipError_t gemv_nw(int nw, GemvArgs a, int B, int K, hipStream_t st) {
     return gemv_groups<WT, 1, 2, PRO, EPI>(a, B, K, st);
 }
 
+// out_proj of 5..8 rows: ONE pass of the VALU kernel with 5..8 accumulators per weight row.  The matrix-core kernel has only 48
+// row tiles for this 1536-row matrix (48 of 256 CUs: 9.3 us at B = 5 against 4.9 us for the four-row VALU launch), which left the
+// aggregate rate of five rows below that of four (profiles/r03_batch_table_v2.log); same per-(row, batch row) arithmetic as every
+// other path.
+template <typename WT>
+static hipError_t gemv_outproj_rows8(const GemvArgs& a, int B, hipStream_t st) {
+    switch (B) {
+        case 5: return launch_gemv<WT, 1, 5, 1, PRO_NONE, EPI_RESID, 3>(a, st);
+        case 6: return launch_gemv<WT, 1, 6, 1, PRO_NONE, EPI_RESID, 3>(a, st);
+        case 7: return launch_gemv<WT, 1, 7, 1, PRO_NONE, EPI_RESID, 3>(a, st);
+        case 8: return launch_gemv<WT, 1, 8, 1, PRO_NONE, EPI_RESID, 3>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 // B > 4: weights streamed once per pass of up to 16 rows (gemv_batched_kernel)
 constexpr int NBB = 16;
 template <typename WT, int PH, int RW, int EPI>
@@ -819,6 +834,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             a.W = HALF ? (const void*)L.wo_h : (const void*)L.wo; a.bias = L.bo; a.N = H; a.xin = c->abuf; a.out = c->ypre1; a.resid = c->hbuf;
             // 48 row tiles of 32: the matrix-core kernel runs on 48 CUs only, but streams the matrix ONCE for 32 rows where the
             // VALU kernel needs a pass per 16
+            if (c->batched && !c->batched_valu && B >= 5 && B <= 8) return gemv_outproj_rows8<WT>(a, B, st);
             if (c->batched && !c->batched_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, c->skpart, st); }
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
             return gemv_groups<WT, 1, 1, PRO_NONE, EPI_RESID, 3>(a, B, H, st);     // 3 waves x 1 row: 512 workgroups = 2 per CU

@@ -39,6 +39,8 @@ struct AttnDecArgs {
     int chunk;             // keys per workgroup (fp32: 32*STEPS, fp16: 64*STEPS with half the steps)
     long long kv_bstride;
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
+    const int* len_src;    // filled by the version-3 launcher: len = len_src[b] + len_add (len_dev + 0, or pos + 1) unless fixed_len > 0
+    int len_add;
 };
 
 __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
@@ -387,21 +389,14 @@ __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
 constexpr int A3_LD = 97;     // row stride of the wave partials in LDS (D + 1: lanes that read a column down the rows hit 32 different banks)
 
 template <typename KT, int D, int NS, int NW>
-__device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, const KT* vb, const float* qp, int k0, int k1,
+__device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, const KT* vb,
+                                           const float (&qv)[D / (KVec<KT>::EPL * KVec<KT>::LPK)][KVec<KT>::EPL], int k0, int k1,
                                            float* ored, float* wm, float* wl, float* po, float* pml) {
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
     constexpr int NV = D / (EPL * LPK);
     constexpr int KPW = 64 / LPK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = lane & (LPK - 1), g = lane / LPK;
-    float qv[NV][EPL];
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < EPL; e += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
-            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
-        }
     f32x4 kreg[NS][NV], vreg[NS][NV];
     bool valid[NS];
 #pragma unroll
@@ -529,26 +524,52 @@ __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(AttnDecArgs a) {
     __shared__ float wm[NW], wl[NW];
     ER_TP(0);
     const int h = blockIdx.x, c = blockIdx.y, b = blockIdx.z, nch = gridDim.y;
-    const int len = attn_len(a, b);
-    const int clen = (len + nch - 1) / nch;                 // <= STEPS * NW * KPW (the launcher checks l_cap)
-    const int k0 = c * clen, k1 = min(len, k0 + clen);
+    // The road to the first K load is a chain of dependent scalar round trips: kernel arguments -> the row's length (a device word the
+    // sampling head wrote) -> chunk bounds -> addresses.  Left alone hipcc walked attn_len's three cases one scalar load at a time,
+    // fetched the cache pointers only behind the early-exit test, and did every address computation (and the q loads) after the
+    // length had arrived: 1140 cycles from "length here" to "loads issued" (profiles/r03_attn_timeline.log).  Here: ONE batch of
+    // argument loads, the length load, then everything that does not depend on it - pointers, the q registers - while it is in
+    // flight; the chunk count is a power of two (16 or 32), so the bounds are shifts.
+    {
+        const void *p0 = a.q, *p1 = a.kcache, *p2 = a.vcache, *p3 = a.part, *p4 = a.part_ml, *p5 = a.len_src;
+        const long long s0 = a.kv_bstride;
+        const int i0 = a.H, i1 = a.l_cap, i2 = a.hidden, i3 = a.fixed_len, i4 = a.len_add;
+        const float f0 = a.sqrt_d;
+        asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(s0), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(f0));
+    }
+    const int lmem = a.len_src[b];
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK);
     float* po = a.part + (((long long)b * a.H + h) * nch + c) * D;
     float* pml = a.part_ml + (((long long)b * a.H + h) * nch + c) * 2;
+    const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
+    const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
+    const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
+    const float* qp = a.q + (long long)b * a.hidden + h * D;
+    float qv[NV][EPL];
+    {
+        const int p = threadIdx.x & (LPK - 1);
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+                qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+            }
+    }
+    const int len = a.fixed_len > 0 ? a.fixed_len : lmem + a.len_add;
+    const int clen = (len + nch - 1) >> __builtin_ctz(nch);      // <= STEPS * NW * KPW (the launcher checks l_cap and that nch is 16 / 32)
+    const int k0 = c * clen, k1 = min(len, k0 + clen);
     if (k0 >= k1) {                                        // empty chunk (len < nch): a partial the merge weighs with exp(-inf) = 0
         if (threadIdx.x < D) po[threadIdx.x] = 0.f;
         if (threadIdx.x == 0) { pml[0] = -INFINITY; pml[1] = 0.f; }
         return;
     }
-    const long long head_off = (long long)b * a.kv_bstride + (long long)h * a.l_cap * D;
-    const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
-    const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
-    const float* qp = a.q + (long long)b * a.hidden + h * D;
     const int nsteps = (k1 - k0 + NW * KPW - 1) / (NW * KPW);      // workgroup-uniform
     ER_TP(1);
-    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else attn3_body<KT, D, 1, NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    else attn3_body<KT, D, 1, NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
 }
 
 constexpr int ATTN3_NW = 16;                   // waves per workgroup of the balanced kernel
@@ -557,9 +578,14 @@ inline int attn3_num_chunks(int heads) { return heads >= 16 ? 16 : 32; }   // H 
 inline bool attn3_fits(int l_cap, int heads) { return l_cap <= attn3_num_chunks(heads) * ATTN3_CAP; }
 
 template <int D>
-inline hipError_t launch_attn_partial3_d(const AttnDecArgs& a, bool kv_half, int nch, int B, hipStream_t st) {
-    if (nch <= 0 || a.l_cap > nch * ATTN3_CAP || !a.part_ml) return hipErrorInvalidValue;   // a chunk must fit one workgroup's wave-steps
-    const dim3 grid(a.H, nch, B), blk(64 * ATTN3_NW);
+inline hipError_t launch_attn_partial3_d(const AttnDecArgs& a_in, bool kv_half, int nch, int B, hipStream_t st) {
+    const AttnDecArgs& a0 = a_in;
+    if ((nch != 16 && nch != 32) || a0.l_cap > nch * ATTN3_CAP || !a0.part_ml || (!a0.pos && !a0.len_dev && a0.fixed_len <= 0)) return hipErrorInvalidValue;   // a chunk must fit one workgroup's wave-steps
+    const dim3 grid(a0.H, nch, B), blk(64 * ATTN3_NW);
+    AttnDecArgs a = a_in;
+    // (with a fixed length and no length array the kernel's unconditional length load reads a word of the partials buffer and ignores it)
+    a.len_src = a.len_dev ? a.len_dev : (a.pos ? a.pos : reinterpret_cast<const int*>(a.part_ml));
+    a.len_add = a.len_dev ? 0 : 1;
     if (!kv_half) hipLaunchKernelGGL((attn_decode3_kernel<float, D, 4, ATTN3_NW>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((attn_decode3_kernel<_Float16, D, 2, ATTN3_NW>), grid, blk, 0, st, a);
     return hipGetLastError();

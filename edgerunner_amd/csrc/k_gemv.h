@@ -71,42 +71,59 @@ __device__ __forceinline__ float dot_w(const f32x4& wraw, const f32x4* x, float 
     }
 }
 
-// bias / residual / cache position are fetched at kernel entry (EpiPre) so that the epilogue after the
-// reduction is pure arithmetic + one store instead of a chain of dependent L2 round trips.
-struct EpiPre { float bias; float resid; int pos; };
+// bias / residual / cache position are fetched at kernel entry (EpiPre) and the destination ADDRESS is finished there too, so that
+// the epilogue after the reduction is one add and one store.  Left to the compiler, the tail of the qkv kernel re-read five kernel
+// arguments (s_load behind the reduction), ran two integer divisions (n / hidden, c / head_dim) and - worse - fetched pos[b] with a
+// SCALAR load issued in the middle of the LayerNorm prologue: scalar loads share lgkmcnt with LDS, so the s_waitcnt before the
+// prologue's first barrier sat out the whole memory round trip of that load (the ~0.9 us the qkv launch was above fc1's shape for
+// shape, round 3).  pos[b] is therefore read with a VECTOR load (an opaque zero in the index keeps hipcc from proving the address
+// uniform): it queues first in vmcnt order and nobody waits for it before the tail.
+struct EpiPre { float bias; float resid; char* dst; int half; int pos; int pos_scale; };   // final address = dst + pos * pos_scale
+
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
 
 template <int EPI>
 __device__ __forceinline__ EpiPre gemv_epi_prefetch(const GemvArgs& a, int n, int b) {
-    EpiPre e{0.f, 0.f, 0};
+    EpiPre e{0.f, 0.f, nullptr, 0, 0, 0};
     n = min(n, a.N - 1);
     if (a.bias) e.bias = a.bias[n];
     if (EPI == EPI_RESID) e.resid = a.resid[(long long)b * a.N + n];
-    if (EPI == EPI_QKV) e.pos = a.pos[b];
+    if (EPI == EPI_QKV) {   // rows [0,hidden) = q, [hidden,2h) = k, [2h,3h) = v
+        e.pos = a.pos[b + opaque_zero()];                  // in flight until the tail: nothing up here may depend on it
+        const int which = n / a.hidden;
+        const int c = n - which * a.hidden;
+        if (which == 0) {
+            e.dst = reinterpret_cast<char*>(a.q + (long long)b * a.hidden + c);
+        } else {
+            const int h = c / a.head_dim, d = c - h * a.head_dim;
+            const int esz = a.kv_half ? 2 : 4;
+            char* cache = reinterpret_cast<char*>((which == 1) ? a.kcache : a.vcache);
+            e.dst = cache + ((long long)b * a.kv_bstride + (long long)h * a.l_cap * a.head_dim + d) * esz;
+            e.pos_scale = a.head_dim * esz;
+            e.half = a.kv_half;
+        }
+    } else {
+        e.dst = reinterpret_cast<char*>(a.out + (long long)b * a.N + n);
+    }
+    unsigned long long pin = reinterpret_cast<unsigned long long>(e.dst);      // keep the address arithmetic up here (machine sinking
+    asm volatile("" : "+v"(pin));                                              // would move it back behind the reduction)
+    e.dst = reinterpret_cast<char*>(pin);
     return e;
 }
 
 template <int EPI>
 __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, float v, const EpiPre& e) {
     v += e.bias;
-    if (EPI == EPI_STORE) {
-        a.out[(long long)b * a.N + n] = v;
-    } else if (EPI == EPI_RELU) {
-        a.out[(long long)b * a.N + n] = fmaxf(v, 0.0f);
-    } else if (EPI == EPI_RESID) {
-        a.out[(long long)b * a.N + n] = v + e.resid;
-    } else {  // EPI_QKV: rows [0,hidden) = q, [hidden,2h) = k, [2h,3h) = v
-        const int which = n / a.hidden;
-        const int c = n - which * a.hidden;
-        if (which == 0) {
-            a.q[(long long)b * a.hidden + c] = v;
-        } else {
-            const int h = c / a.head_dim, d = c - h * a.head_dim;
-            void* cache = (which == 1) ? a.kcache : a.vcache;
-            const long long idx = (long long)b * a.kv_bstride + ((long long)h * a.l_cap + e.pos) * a.head_dim + d;
-            if (a.kv_half) reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)v;     // round-to-nearest-even
-            else reinterpret_cast<float*>(cache)[idx] = v;
-        }
-    }
+    if (EPI == EPI_RELU) v = fmaxf(v, 0.0f);
+    if (EPI == EPI_RESID) v += e.resid;
+    char* dst = e.dst;
+    if (EPI == EPI_QKV) dst += (long long)e.pos * e.pos_scale;
+    if (EPI == EPI_QKV && e.half) *reinterpret_cast<_Float16*>(dst) = (_Float16)v;     // round-to-nearest-even
+    else *reinterpret_cast<float*>(dst) = v;
 }
 
 // K = KS * 1536 (a wave reduces one 1536-slice = J 16-byte loads per lane, J = 6 for fp32 weights,

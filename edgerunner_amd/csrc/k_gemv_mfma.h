@@ -65,7 +65,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     const int ot = slot / NBH, oh = slot - ot * NBH;
     const int on = n0 + 16 * ot + 4 * (ol >> 4) + orr, ob = oh * 16 + (ol & 15);
     const bool active = slot < GM_R2 * NBH && on < a.N && ob < nb_valid;
-    EpiPre pre{0.f, 0.f, 0};
+    EpiPre pre{0.f, 0.f, nullptr, 0, 0, 0};
     if (!SPLIT && active) pre = gemv_epi_prefetch<EPI>(a, on, ob);
 
     // keep every load above the first MFMA: without this the scheduler sinks the loads next to their uses to save
