@@ -473,8 +473,9 @@ __global__ __launch_bounds__(ER_WG) void prep_rows_kernel(GemvArgs a) {
         for (int i = 0; i < PT; ++i) v[i] = e[tid + i * ER_WG] + p[tid + i * ER_WG];
     } else {
         const float* x = a.xin + (long long)b * K;
+        float lw[PT], lb[PT];                  // loaded with the row, not behind the two reductions (a dependent round trip per launch)
 #pragma unroll
-        for (int i = 0; i < PT; ++i) v[i] = x[tid + i * ER_WG];
+        for (int i = 0; i < PT; ++i) { v[i] = x[tid + i * ER_WG]; lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG]; }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < PT; ++i) s += v[i];
@@ -485,10 +486,7 @@ __global__ __launch_bounds__(ER_WG) void prep_rows_kernel(GemvArgs a) {
         const float var = block_sum(s2, red) / (float)K;
         const float rstd = 1.0f / sqrtf(var + a.eps);
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const int c = tid + i * ER_WG;
-            v[i] = (v[i] - mean) * rstd * a.ln_w[c] + a.ln_b[c];
-        }
+        for (int i = 0; i < PT; ++i) v[i] = (v[i] - mean) * rstd * lw[i] + lb[i];
     }
 #pragma unroll
     for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * ER_WG] = v[i];

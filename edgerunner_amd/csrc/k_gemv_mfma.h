@@ -168,7 +168,10 @@ __global__ __launch_bounds__(ER_WG) void tile_weights_kernel(const WT* src, f32x
 template <typename WT>
 inline size_t tiled_weight_bytes(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K * sizeof(WT); }
 
-// out(b, n) = epilogue(sum_s part[s][b][n]) in slice order
+// out(b, n) = epilogue(sum_s part[s][b][n]) in slice order.  (Round 3 tried this finish fused with the NEXT layer's LayerNorm - one
+// workgroup per batch row, saving the prep_rows launch in front of qkv: measured SLOWER, 12.7 -> 18.5 us for fc2 against 11.6 -> 9.3
+// for qkv at B = 5, configs[3] 7023 -> 6944 tok/s: B workgroups walking the slices serially lose more than a launch costs;
+// profiles/r03_splitk_finish_ln_fused.log.)
 template <int EPI>
 __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const float* part, int S, int nb_valid) {
     const long long i = (long long)blockIdx.x * ER_WG + threadIdx.x;
