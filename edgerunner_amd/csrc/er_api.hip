@@ -944,7 +944,7 @@ static int linear_hs(er_ctx* c, const float* A, int lda, const _Float16* W, cons
     ERCHK(ensure(c->p_lo, (size_t)M * K / 2 + 8));
     _Float16* hi = reinterpret_cast<_Float16*>(c->p_hi.p);
     _Float16* lo = reinterpret_cast<_Float16*>(c->p_lo.p);
-    hipLaunchKernelGGL(split_rows_f16_kernel, dim3(ew_grid((long long)M * K / 4)), dim3(ER_WG), 0, st, A, hi, lo, (long long)M, K, lda);
+    hipLaunchKernelGGL(split_rows_f16_kernel, split_rows_grid(M, K), dim3(ER_WG), 0, st, A, hi, lo, (long long)M, K, lda);
     HIPRET(hipGetLastError());
     GemmArgs g = gemm_args_default();
     g.A = reinterpret_cast<const float*>(hi); g.a_lo = lo; g.B = reinterpret_cast<const float*>(W); g.C = C; g.bias = bias; g.resid = resid;
@@ -1148,7 +1148,7 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
             ERCHK(ensure(c->p_qkv, (size_t)M * 3 * H));
             float* qkv = c->p_qkv.p;
             ERCHK(linear_hs(c, h, H, L.wqkv_h, L.bqkv, qkv, 3 * H, M, 3 * H, H, false, nullptr, 0, st));
-            hipLaunchKernelGGL(kv_scatter_half_kernel, dim3(ew_grid((long long)M * 2 * H)), dim3(ER_WG), 0, st, qkv,
+            hipLaunchKernelGGL(kv_scatter_half_kernel, kv_scatter_grid(M, H), dim3(ER_WG), 0, st, qkv,
                                (_Float16*)kc, (_Float16*)vc, M, S, H, D, c->Lcap, c->kv_bstride);
             HIPRET(hipGetLastError());
             {
@@ -1629,7 +1629,7 @@ extern "C" int er_k_gemm_f16s(const float* a, const void* w, const float* bias, 
         _Float16 *hi = nullptr, *lo = nullptr;
         HIPCHK(hipMalloc(&hi, (size_t)m * k * 2));
         HIPCHK(hipMalloc(&lo, (size_t)m * k * 2));
-        hipLaunchKernelGGL(split_rows_f16_kernel, dim3(ew_grid((long long)m * k / 4)), dim3(ER_WG), 0, st, a, hi, lo, (long long)m, k, lda);
+        hipLaunchKernelGGL(split_rows_f16_kernel, split_rows_grid(m, k), dim3(ER_WG), 0, st, a, hi, lo, (long long)m, k, lda);
         g.A = reinterpret_cast<const float*>(hi); g.a_lo = lo; g.lda = k;
         hipError_t e = launch_gemm_hh_split(g, st);
         hipError_t e2 = hipStreamSynchronize(st);

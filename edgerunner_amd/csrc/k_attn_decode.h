@@ -342,9 +342,10 @@ __device__ __forceinline__ void combine_pass(const float* pb, int base, int n_ac
     const float l_blk = wave_sum(l_s * w);
     const float alpha = (M_run == -INFINITY) ? 0.f : expf(M_run - M_new);
     float o = o_run * alpha;
+    const int hs = __builtin_amdgcn_readfirstlane(half);         // wave-uniform: the weights come through v_readlane, not the LDS crossbar
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const float wu = __shfl(w, half + 2 * u, 64);            // 0 for partials beyond n_act
+        const float wu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), hs + 2 * u));   // 0 for partials beyond n_act
         o = fmaf(v[u], wu, o);
     }
     o_run = o;

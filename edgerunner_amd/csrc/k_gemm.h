@@ -142,6 +142,10 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int GLT = GBM + 1, GLTB = GBN + 1;
     __shared__ __attribute__((aligned(16))) float As[2][GBK * GLT];
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    // gfx950 only (the build targets nothing else, edgerunner_amd/build.py): the 128 x 128 tile's two stages are 66.8 KB of static LDS -
+    // above the 64 KB a workgroup may hold on gfx90a / gfx942, inside the 160 KB of a gfx950 CU, where they leave room for TWO
+    // workgroups per CU (gemm_pick_tile's "three per CU" counts workgroups per CU of the GRID, not resident ones)
+    static_assert(sizeof(float) * 2 * GBK * (GLT + GLD) <= 80 * 1024, "two workgroups of this tile must fit the 160 KB LDS of a gfx950 CU");
     const int ldbs = g.b_is_kn ? GLD : GLTB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -784,17 +788,20 @@ inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st, int force_ti
 
 // x (fp32 rows) -> hi = fp16(x), lo = fp16(x - hi): the two A operands of the split form (exactly the split the register-staged
 // gemm_f16s_mfma_kernel performs on its way into LDS)
+// grid (ceil(cols / 4 / 256), rows' worth of blocks): a row per blockIdx.y (strided), a float4 per thread - no index division
 __global__ __launch_bounds__(ER_WG) void split_rows_f16_kernel(const float* x, _Float16* hi, _Float16* lo, long long rows, int cols, int ldx) {
-    const long long total = rows * (cols / 4);
-    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
-        const long long r = i / (cols / 4);
-        const int c = (int)(i - r * (cols / 4)) * 4;
+    const int c = (blockIdx.x * ER_WG + threadIdx.x) * 4;
+    if (c >= cols) return;
+    for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
         const h16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         const h16x4 l = {(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
         *reinterpret_cast<h16x4*>(hi + r * cols + c) = h;
         *reinterpret_cast<h16x4*>(lo + r * cols + c) = l;
     }
+}
+inline dim3 split_rows_grid(long long rows, int cols) {
+    return dim3((unsigned)((cols / 4 + ER_WG - 1) / ER_WG), (unsigned)(rows < 65535 ? (rows > 0 ? rows : 1) : 65535));
 }
 
 // split form: A = a_hi (g.A) + a_lo (g.a_lo), fp16 [M][lda]; 64-row tiles

@@ -174,12 +174,20 @@ inline size_t tiled_weight_bytes(int N, int K) { return (size_t)((N + 15) / 16) 
 // profiles/r03_splitk_finish_ln_fused.log.)
 template <int EPI>
 __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const float* part, int S, int nb_valid) {
-    const long long i = (long long)blockIdx.x * ER_WG + threadIdx.x;
-    if (i >= (long long)nb_valid * a.N) return;
-    const int b = (int)(i / a.N), n = (int)(i - (long long)b * a.N);
+    const unsigned i = blockIdx.x * ER_WG + threadIdx.x;          // nb_valid <= 32 rows x N columns: 32-bit (a 64-bit division is ~100 instructions)
+    if (i >= (unsigned)nb_valid * (unsigned)a.N) return;
+    const int b = (int)(i / (unsigned)a.N), n = (int)(i - (unsigned)b * (unsigned)a.N);
     const EpiPre pre = gemv_epi_prefetch<EPI>(a, n, b);
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[((long long)k * nb_valid + b) * a.N + n];
+    if (S == 4) {          // fc2: the four slices' loads go out together (the generic loop is four dependent round trips); same order of adds
+        float p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = part[((long long)k * nb_valid + b) * a.N + n];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += p[k];
+    } else {
+        for (int k = 0; k < S; ++k) s += part[((long long)k * nb_valid + b) * a.N + n];
+    }
     gemv_epilogue<EPI>(a, n, b, s, pre);
 }
 

@@ -18,10 +18,16 @@ __global__ __launch_bounds__(ER_WG) void layernorm_rows_kernel(const float* x, c
     const int r = blockIdx.x * ER_NWAVES + (threadIdx.x >> 6);
     if (r >= rows) return;
     const float* xr = x + (long long)r * ldx;
-    float v[CPL];
+    // every load up front: y may alias x and w / b are not restrict-qualified, so left in the store loop the affine parameters
+    // would be fetched one column group at a time BEHIND the previous group's stores (18 us per launch for 25 MB in round 2)
+    float v[CPL], wv[CPL], bv[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = xr[lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { wv[i] = w[lane + 64 * i]; bv[i] = b[lane + 64 * i]; }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+    for (int i = 0; i < CPL; ++i) s += v[i];
     const float mean = wave_sum(s) / (float)COLS;
     float s2 = 0.f;
 #pragma unroll
@@ -29,10 +35,7 @@ __global__ __launch_bounds__(ER_WG) void layernorm_rows_kernel(const float* x, c
     const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)COLS + eps);
     float* yr = y + (long long)r * ldy;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const int c = lane + 64 * i;
-        yr[c] = (v[i] - mean) * rstd * w[c] + b[c];
-    }
+    for (int i = 0; i < CPL; ++i) yr[lane + 64 * i] = (v[i] - mean) * rstd * wv[i] + bv[i];
 }
 
 inline hipError_t launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int cols,
@@ -168,22 +171,29 @@ __global__ __launch_bounds__(ER_WG) void gather_rows_kernel(const float* table, 
 // Fast mode prefill: move the K/V columns of the fused projection output qkv[M][3*hidden] into the fp16
 // cache [B][H][Lcap][D] (what modeling_opt.py:189-192 stores, in the reference's GPU dtype) and round the
 // scratch copy through fp16 in place, so the prefix attention sees exactly the values later steps will read.
+// grid (ceil(2 * hidden / 4 / 256), rows): a token row per blockIdx.y (strided), four consecutive columns per thread (head_dim % 4 == 0:
+// they stay inside one head).  Round 2's element-per-thread form with a 64-bit and two 32-bit index divisions per ELEMENT was
+// bound by its index arithmetic: 26 us per layer for 63 MB (profiles/r02_prefill_fp16_kernel_stats.csv).
 __global__ __launch_bounds__(ER_WG) void kv_scatter_half_kernel(float* qkv, _Float16* kcache, _Float16* vcache, int M,
                                                                 int S, int hidden, int head_dim, int l_cap,
                                                                 long long kv_bstride) {
-    const long long total = (long long)M * 2 * hidden;
-    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
-        const long long m = i / (2 * hidden);
-        const int c2 = (int)(i - m * 2 * hidden);
-        const int which = c2 / hidden, c = c2 - which * hidden;       // 0 = K, 1 = V
-        const int b = (int)(m / S), s = (int)(m - (long long)b * S);
-        const int h = c / head_dim, d = c - h * head_dim;
-        float* src = qkv + m * 3 * hidden + hidden + c2;
-        const _Float16 hv = (_Float16)*src;
-        *src = (float)hv;
-        _Float16* cache = which == 0 ? kcache : vcache;
-        cache[(long long)b * kv_bstride + ((long long)h * l_cap + s) * head_dim + d] = hv;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const int c2 = (blockIdx.x * ER_WG + threadIdx.x) * 4;
+    if (c2 >= 2 * hidden) return;
+    const int which = c2 >= hidden ? 1 : 0, c = c2 - which * hidden;       // 0 = K, 1 = V
+    const int h = c / head_dim, d = c - h * head_dim;
+    _Float16* cache = which == 0 ? kcache : vcache;
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        const int b = m / S, s = m - b * S;
+        f32x4* src = reinterpret_cast<f32x4*>(qkv + (long long)m * 3 * hidden + hidden + c2);
+        const f32x4 v = *src;
+        const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *src = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        *reinterpret_cast<h4*>(cache + (long long)b * kv_bstride + ((long long)h * l_cap + s) * head_dim + d) = hv;
     }
+}
+inline dim3 kv_scatter_grid(int M, int hidden) {
+    return dim3((unsigned)((2 * hidden / 4 + ER_WG - 1) / ER_WG), (unsigned)(M < 65535 ? (M > 0 ? M : 1) : 65535));
 }
 
 inline int ew_grid(long long total) {

@@ -32,7 +32,8 @@ __device__ unsigned long long* g_tp_out;
 // the library kernel + a tail that copies the stamps out: launch index travels in a.S (unused by version 3)
 template <typename KT, int STEPS>
 __global__ __launch_bounds__(64 * ATTN3_NW) void attn3_timed(AttnDecArgs a) {
-    // same body as attn_decode3_kernel (k_attn_decode.h), which cannot be called as a function: restated dispatch, shared arrays here
+    // same body as attn_decode3_kernel (k_attn_decode.h), which cannot be called as a function: restated dispatch (round-2 form of the
+    // entry: the library kernel now batches its argument loads and hoists the length-independent work), shared arrays here
     constexpr int D = 96, NW = ATTN3_NW;
     constexpr int KPW = 64 / KVec<KT>::LPK;
     __shared__ __attribute__((aligned(16))) float ored[NW * 4 * A3_LD];
@@ -48,12 +49,24 @@ __global__ __launch_bounds__(64 * ATTN3_NW) void attn3_timed(AttnDecArgs a) {
     const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
     const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
     const float* qp = a.q + (long long)b * a.hidden + h * D;
+    constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK);
+    float qv[NV][EPL];
+    {
+        const int p = threadIdx.x & (LPK - 1);
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+                qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+            }
+    }
     const int nsteps = (k1 - k0 + NW * KPW - 1) / (NW * KPW);
     ER_TP(1);
-    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
-    else attn3_body<KT, D, 1, NW>(a, kb, vb, qp, k0, k1, ored, wm, wl, po, pml);
+    if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    else attn3_body<KT, D, 1, NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
     if (threadIdx.x == 0) {
         unsigned long long* o = g_tp_out + ((long long)a.S * 256 + (blockIdx.x + 16 * blockIdx.y)) * 10;
         for (int i = 0; i < 10; ++i) o[i] = er_tp_dyn[i];
