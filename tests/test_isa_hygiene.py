@@ -1,0 +1,110 @@
+"""Code-generation guards for the decode hot path (no GPU needed: hipcc cross-compiles gfx950 here).
+
+Round 3 found 5 % of configs[1] in things the ISA showed and the source did not: wave reductions lowered to
+dependent ds_bpermute round trips, a scalar load of pos[b] stalling the LayerNorm prologue through the shared lgkmcnt, kernel
+arguments and integer divisions sunk behind the final reduction, a vmcnt(0) in front of the weight stream, 64-bit index divisions
+per element.  These tests compile csrc/er_api.hip to device assembly once and assert that none of them is back."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "edgerunner_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    """{mangled kernel name: [instruction lines]} of the gfx950 code object."""
+    from edgerunner_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "er_api.s"
+    flags = [f for f in B.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", "-o", str(out), "er_api.hip"], check=True, cwd=CSRC,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    funcs = {}
+    for name, body in re.findall(r"\n(_Z[^\n:]*):\s*; @[^\n]*\n(.*?)s_endpgm", text, flags=re.S):
+        funcs[name] = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith((";", "."))]
+    assert len(funcs) > 200, "device assembly not parsed"
+    return funcs
+
+
+def select(kernels, pattern):
+    sel = {n: b for n, b in kernels.items() if re.search(pattern, n)}
+    assert sel, f"no kernel matches {pattern}"
+    return sel
+
+
+def count(body, needle):
+    return sum(needle in l for l in body)
+
+
+def test_no_lds_crossbar_in_wave_reductions(kernels):
+    """er_common.h's butterflies run on v_permlane*_swap + DPP; a ds_bpermute in these kernels means a __shfl crept back in."""
+    hot = select(kernels, r"gemv_kernelI|attn_decode3_kernel|attn_decode2_kernel|attn_decode_kernelI|attn_stream_kernel|"
+                          r"attn_combine2_kernel|sample_head_kernel|flash_attn_f32_kernel|flash_attn_f16s_kernel|gemv_batched_kernel|"
+                          r"prep_rows_kernel|layernorm_rows_kernel|ln_modulate_rows_kernel")
+    bad = {n: count(b, "ds_bpermute") for n, b in hot.items() if count(b, "ds_bpermute")}
+    assert not bad, bad
+    for n, b in select(kernels, r"outproj_merge_kernel").items():
+        assert count(b, "ds_bpermute") <= 16, (n, "only the 16 weight broadcasts may use the crossbar")
+        assert count(b, "v_permlane16_swap") >= 2, n
+
+
+def single_row_gemvs(kernels):
+    # gemv_kernel<WT, KS = 1, NB, RW, PRO, EPI, NW>: the LayerNorm-prologue / plain single-row kernels of the decode step
+    return select(kernels, r"gemv_kernelI(f|DF16_)Li1ELi[1-8]ELi[12]ELi[012]ELi[0123]ELi\d+EEE")
+
+
+def test_gemv_tail_is_arithmetic_and_one_store(kernels):
+    """Behind the final 64-lane reduction: no kernel-argument loads, no integer division (the destination address is finished at
+    entry, k_gemv.h gemv_epi_prefetch)."""
+    for n, b in single_row_gemvs(kernels).items():
+        last = max(i for i, l in enumerate(b) if "v_permlane32_swap" in l)
+        tail = b[last:]
+        assert not [l for l in tail if l.startswith("s_load")], (n, "s_load behind the reduction")
+        assert not count(tail, "v_rcp_iflag"), (n, "integer division behind the reduction")
+        assert len(tail) < 200, (n, len(tail))
+
+
+def test_gemv_weight_stream_is_issued_before_any_drain(kernels):
+    """No s_waitcnt vmcnt(0) in front of the last weight load: everything the prologue / epilogue needs queues FIRST in vmcnt order,
+    and nothing up there may depend on the position word (a pin on pos-dependent address arithmetic once put a drain here)."""
+    for n, b in single_row_gemvs(kernels).items():
+        w = [i for i, l in enumerate(b) if l.startswith("global_load_dwordx4") and l.endswith(" nt")]
+        assert w, (n, "weight loads are nontemporal dwordx4 loads")
+        drains = [i for i, l in enumerate(b[:w[-1]]) if re.match(r"s_waitcnt vmcnt\(0\)", l)]
+        assert not drains, (n, drains)
+
+
+def test_qkv_position_word_is_a_vector_load(kernels):
+    """pos[b] of the KV-append epilogue must not be a scalar load: scalar loads share lgkmcnt with LDS, and the wait in front of
+    the LayerNorm prologue's first barrier then sits out its memory round trip."""
+    qkv = select(kernels, r"gemv_kernelI(f|DF16_)Li1ELi1ELi[12]ELi1ELi3ELi\d+EEE")       # PRO_LN, EPI_QKV, one row
+    for n, b in qkv.items():
+        first_w = min(i for i, l in enumerate(b) if l.startswith("global_load_dwordx4") and l.endswith(" nt"))
+        scalar_data_loads = [l for l in b[first_w:] if re.match(r"s_load_dword s\d+, s\[\d+:\d+\], 0x0$", l)]
+        assert not scalar_data_loads, (n, scalar_data_loads)
+
+
+def test_attention_entry_loads_its_arguments_once(kernels):
+    """attn_decode3_kernel: one batch of kernel-argument loads, then the length; nothing is fetched behind the early-exit test."""
+    for n, b in select(kernels, r"attn_decode3_kernel").items():
+        first = min(i for i, l in enumerate(b) if l.startswith("global_load"))
+        late = [l for l in b[first:] if l.startswith("s_load")]
+        assert not late, (n, late)
+        assert not count(b[:200], "v_rcp_iflag"), (n, "chunk bounds are shifts, not divisions")
+
+
+def test_row_kernels_have_no_per_element_index_division(kernels):
+    """Element-wise kernels of the per-layer prefill path take a row per block and a float4 per thread; a 64-bit index division
+    per element made kv_scatter_half_kernel compute-bound (26 us per layer for 63 MB)."""
+    limits = {r"kv_scatter_half_kernel": 140, r"split_rows_f16_kernel": 140, r"splitk_finish_kernelILi2E": 200}
+    for pat, lim in limits.items():
+        for n, b in select(kernels, pat).items():
+            assert len(b) < lim, (n, len(b))
