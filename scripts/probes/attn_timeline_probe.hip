@@ -195,6 +195,29 @@ int main(int argc, char** argv) {
     }
     printf("boundary filler-exit -> first attention entry %.2f us | entry skew %.2f us | first entry -> last exit %.2f us | exit skew %.2f us\n",
            bnd / n, skew / n, tot / n, exitskew / n);
+    // where does the exit skew come from?  exit time (us after the launch's first entry) by XCD (= head % 8: workgroup (h, c) is number
+    // h + 16 c of the grid) and by chunk index, mean over the launches
+    {
+        double xs[8] = {0}, xm[8] = {0}, cs[16] = {0}, es[8] = {0};
+        int nl = 0;
+        for (int l = 4; l < NL; ++l, ++nl) {
+            unsigned long long smin = ~0ull;
+            for (int w = 0; w < 256; ++w) smin = std::min(smin, h[((size_t)l * 256 + w) * 10 + 8]);
+            double lx[8] = {0};
+            for (int w = 0; w < 256; ++w) {
+                const unsigned long long* t = &h[((size_t)l * 256 + w) * 10];
+                const int hh = w & 15, cc = w >> 4;
+                const double ex = (double)(t[9] - smin) / 100.0, en = (double)(t[8] - smin) / 100.0;
+                xs[hh & 7] += ex / 32.0; lx[hh & 7] = std::max(lx[hh & 7], ex); cs[cc] += ex / 16.0; es[hh & 7] += en / 32.0;
+            }
+            for (int x = 0; x < 8; ++x) xm[x] += lx[x];
+        }
+        printf("exit time by XCD  (mean | last, us after first entry; entry mean):");
+        for (int x = 0; x < 8; ++x) printf("  x%d %.2f|%.2f (%.2f)", x, xs[x] / nl, xm[x] / nl, es[x] / nl);
+        printf("\nexit time by chunk (mean, us):");
+        for (int c = 0; c < 16; ++c) printf(" %.2f", cs[c] / nl);
+        printf("\n");
+    }
     const char* names[8] = {"entry", "pos loaded", "loads issued", "K landed, scores+max", "V landed, P.V", "barrier passed", "(unused)", "stored"};
     printf("stamps relative to the workgroup's entry, shader-clock cycles (mean over workgroups | max):\n");
     for (int i = 1; i < 8; ++i) printf("  %d %-22s %8.0f | %8.0f\n", i, names[i], acc[i] / n, mx[i] / n);
