@@ -126,19 +126,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return r;
 }
 
-// Same sum (identical order) through a caller-chosen 4-float slot and WITHOUT the trailing barrier: successive
-// reductions use different slots, so one barrier per reduction is enough.
-template <int NW = ER_NWAVES>
-__device__ __forceinline__ float block_sum_slot(float v, float* slot, bool writer = true) {   // writer: wave-uniform, false for waves beyond NW
-    static_assert(NW == 3 || NW == 4, "3- or 4-wave reductions");
-    v = wave_sum(v);
-    if (writer && (threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (NW == 3) return (slot[0] + slot[1]) + slot[2];
-    return (slot[0] + slot[1]) + (slot[2] + slot[3]);
-}
-
-// NB such sums behind ONE barrier (slot of sum b: slots + stride * b); same per-sum order as block_sum_slot
+// NB such sums behind ONE barrier and WITHOUT a trailing one (successive reductions use different slots; slot of sum b: slots +
+// stride * b); same per-sum order as block_sum
 template <int NW, int NB>
 __device__ __forceinline__ void block_sum_slots(float (&v)[NB], float* slots, int stride, bool writer) {
     static_assert(NW == 3 || NW == 4, "3- or 4-wave reductions");

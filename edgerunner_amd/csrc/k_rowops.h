@@ -106,19 +106,6 @@ __global__ __launch_bounds__(ER_WG) void geglu_kernel(const float* u, float* out
     }
 }
 
-// the same with the result rounded to fp16 only (it feeds one fp16 Linear and nothing else: DiT feed-forward, fp16 mode)
-__global__ __launch_bounds__(ER_WG) void geglu_f16_kernel(const float* u, _Float16* out, long long rows, int F) {
-    const long long total = rows * F;
-    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
-        const long long m = i / F;
-        const int j = (int)(i - m * F);
-        const float x = u[m * 2 * F + j];
-        const float gt = u[m * 2 * F + F + j];
-        const float gelu = gt * 0.5f * (1.0f + erff(gt * 0.70710678118654752440f));
-        out[i] = (_Float16)(x * gelu);
-    }
-}
-
 // hidden = inputs_embeds + embed_positions(arange(S))   (core/transformer/modeling_opt.py:355-357)
 __global__ __launch_bounds__(ER_WG) void add_pos_kernel(const float* emb, const float* pos, float* out, int B, int S,
                                                         int C, int pos0) {
