@@ -5,6 +5,11 @@
 #   pmc     separate --pmc FETCH_SIZE / WRITE_SIZE passes, configs[1]    -> gpurun_out/r03_pmc_hbm_summary.json
 #   bench3 / prof3 / pmc3   the same for --config 3 (32 clouds per GPU, fp16)
 #   bench2  python bench.py --config 2 (B = 32 sample mode, T = 16000)   -> gpurun_out/r03_bench_config2.json
+#   suite   the whole GPU test suite (~5.5 min)                          -> gpurun_out/r03_gpu_tests.log
+#   tests   kernel units + end-to-end parity only (~2.5 min)             -> gpurun_out/r03_gpu_tests_quick.log
+#   batch   scripts/bench_batch.py, B = 1..32, T = 1000, fp32 and fp16   -> gpurun_out/r03_batch_table_v2.log
+#   dit     DiT tests + scripts/bench_dit.py 16 10 fp16                  -> gpurun_out/r03_dit.log
+#   prefill scripts/prefill_time.py (fp16 B = 1, 8; fp32 B = 1)          -> gpurun_out/r03_prefill_time_final.log
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -14,6 +19,14 @@ for SEC in "$@"; do
     bench)  timeout 900 python bench.py 2> gpurun_out/r03_bench.err | tail -1 > gpurun_out/r03_bench.json; filt < gpurun_out/r03_bench.err | tail -5; head -c 600 gpurun_out/r03_bench.json; echo ;;
     bench3) timeout 900 python bench.py --config 3 --steps 1 --warmup 1 2> gpurun_out/r03_bench3.err | tail -1 > gpurun_out/r03_bench_config3.json; filt < gpurun_out/r03_bench3.err | tail -3; head -c 600 gpurun_out/r03_bench_config3.json; echo ;;
     bench2) timeout 1500 python bench.py --config 2 --steps 1 --warmup 0 2> gpurun_out/r03_bench2.err | tail -1 > gpurun_out/r03_bench_config2.json; filt < gpurun_out/r03_bench2.err | tail -3; head -c 600 gpurun_out/r03_bench_config2.json; echo ;;
+    suite)  timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 -x 2>&1 | filt | tail -15 | tee gpurun_out/r03_gpu_tests.log ;;
+    tests)  timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider --timeout 900 -x 2>&1 | filt | tail -8 | tee gpurun_out/r03_gpu_tests_quick.log ;;
+    batch)  { timeout 400 python scripts/bench_batch.py 1,2,3,4,5,6,7,8,12,16,32 1000 1000 fp32 2>&1 | filt
+              timeout 400 python scripts/bench_batch.py 1,2,3,4,5,6,7,8,12,16,32 1000 1000 fp16 2>&1 | filt; } | tee gpurun_out/r03_batch_table_v2.log | grep aggregate | cut -c1-200 ;;
+    dit)    { timeout 600 python -m pytest tests/test_gpu_dit.py -q -m gpu -s -p no:cacheprovider --timeout 400 2>&1 | filt | tail -12
+              timeout 300 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1; } | tee gpurun_out/r03_dit.log ;;
+    prefill) { timeout 200 python scripts/prefill_time.py fp16 1,8 2>&1 | filt | tail -2
+               timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; } | tee gpurun_out/r03_prefill_time_final.log ;;
     prof|prof3)
       if [ $SEC = prof ]; then TAG=bench; ARGS="--no-fast-extra --cpu-steps 0"; else TAG=config3; ARGS="--config 3"; fi
       rm -rf /tmp/prof_$TAG
