@@ -1,0 +1,34 @@
+"""The committed evidence must reproduce itself: `roofline.frac` of the committed bench lines from the committed rocprofv3 kernel
+summaries (scripts/roofline_from_rocprof.py, what a reviewer runs), and the PMC traffic the bench line quotes from the committed
+PMC summary."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+@pytest.mark.parametrize("csv,line", [("r03_bench_kernel_stats.csv", "r03_bench.json"),
+                                      ("r03_config3_kernel_stats.csv", "r03_bench_config3.json")])
+def test_roofline_reproduces_from_rocprof_summary(csv, line):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "roofline_from_rocprof.py"), os.path.join(PROF, csv),
+                        os.path.join(PROF, line), "--tol", "0.05"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.strip().endswith("OK"), r.stdout[-500:]
+
+
+def test_bench_line_is_internally_consistent():
+    d = json.load(open(os.path.join(PROF, "r03_bench.json")))
+    r = d["roofline"]
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert abs(r["bytes_per_launch"] / (r["avg_us_per_launch"] * 1e-6) / 1e9 - r["achieved"]) < 0.01 * r["achieved"]
+    assert r["traffic"] is not None and 0.95 < r["traffic"] / r["bytes_per_launch"] < 1.10, "PMC traffic ~ algorithmic bytes"
+    assert abs(d["value"] - d["config"]["tokens_per_sample"] * d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    ws = r["whole_step"]
+    assert ws["frac"] <= 1.0 and abs(ws["achieved_GBps"] / 8000.0 - ws["frac"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and "full_run" in cb
