@@ -86,14 +86,23 @@ __device__ __forceinline__ int opaque_zero() {
     return z;
 }
 
+// The two halves of the prefetch: the LOADS (bias, residual, position) are issued in front of the weight stream, the address
+// ARITHMETIC (two integer divisions per row for EPI_QKV, ~100 instructions) behind it - it has until the tail, and in front of the
+// weight loads it would only delay their issue.
 template <int EPI>
-__device__ __forceinline__ EpiPre gemv_epi_prefetch(const GemvArgs& a, int n, int b) {
+__device__ __forceinline__ EpiPre gemv_epi_loads(const GemvArgs& a, int n, int b) {
     EpiPre e{0.f, 0.f, nullptr, 0, 0, 0};
     n = min(n, a.N - 1);
     if (a.bias) e.bias = a.bias[n];
     if (EPI == EPI_RESID) e.resid = a.resid[(long long)b * a.N + n];
+    if (EPI == EPI_QKV) e.pos = a.pos[b + opaque_zero()];      // in flight until the tail: nothing before it may depend on it
+    return e;
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemv_epi_address(const GemvArgs& a, int n, int b, EpiPre& e) {
+    n = min(n, a.N - 1);
     if (EPI == EPI_QKV) {   // rows [0,hidden) = q, [hidden,2h) = k, [2h,3h) = v
-        e.pos = a.pos[b + opaque_zero()];                  // in flight until the tail: nothing up here may depend on it
         const int which = n / a.hidden;
         const int c = n - which * a.hidden;
         if (which == 0) {
@@ -112,6 +121,12 @@ __device__ __forceinline__ EpiPre gemv_epi_prefetch(const GemvArgs& a, int n, in
     unsigned long long pin = reinterpret_cast<unsigned long long>(e.dst);      // keep the address arithmetic up here (machine sinking
     asm volatile("" : "+v"(pin));                                              // would move it back behind the reduction)
     e.dst = reinterpret_cast<char*>(pin);
+}
+
+template <int EPI>
+__device__ __forceinline__ EpiPre gemv_epi_prefetch(const GemvArgs& a, int n, int b) {
+    EpiPre e = gemv_epi_loads<EPI>(a, n, b);
+    gemv_epi_address<EPI>(a, n, b, e);
     return e;
 }
 
@@ -181,10 +196,21 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) pre[r][b] = gemv_epi_prefetch<EPI>(a, row0 + r, b);
+            for (int b = 0; b < NB; ++b) pre[r][b] = gemv_epi_loads<EPI>(a, row0 + r, b);
     } else {
         const int t = min(tid, RW * NB - 1);
-        pre[0][0] = gemv_epi_prefetch<EPI>(a, row0 + t / NB, t % NB);
+        pre[0][0] = gemv_epi_loads<EPI>(a, row0 + t / NB, t % NB);
+    }
+    // PRO_NONE reads its input straight from global memory: the first batch row's slice goes out IN FRONT of the weight stream like
+    // every other small operand (read in the main loop it queued behind the weights, and hipcc then interleaved the six loads with
+    // the first FMAs - a chain of L2 round trips AFTER the last weight byte had landed; fc2 and the out_proj of 2..8 rows)
+    f32x4 x0[PRO == PRO_NONE ? J * XV : 1];
+    if constexpr (PRO == PRO_NONE) {
+        const float* xsrc = a.xin + slice * SL;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int u = 0; u < XV; ++u) x0[j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
     }
     f32x4 w[RW][J];
 #pragma unroll
@@ -195,6 +221,16 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
         for (int j = 0; j < J; ++j) w[r][j] = __builtin_nontemporal_load(wr + j * 64 + lane);
     }
     __builtin_amdgcn_sched_barrier(0);         // keep the whole stream issued before the prologue arithmetic
+    if (KS == 1) {                             // destination addresses of the epilogue: behind the weight issue, long before the tail
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) gemv_epi_address<EPI>(a, row0 + r, b, pre[r][b]);
+    } else {
+        const int t = min(tid, RW * NB - 1);
+        gemv_epi_address<EPI>(a, row0 + t / NB, t % NB, pre[0][0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- prologue: build the input vector(s) in LDS (PRO_NONE reads them straight into the
     // dot-product register layout below: no staging, no barrier).  The statistics of all NB rows share their barriers: one for
@@ -259,8 +295,12 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
-            for (int u = 0; u < XV; ++u)
+            for (int u = 0; u < XV; ++u) {
+                if constexpr (PRO == PRO_NONE) {
+                    if (b == 0) { xr[j * XV + u] = x0[j * XV + u]; continue; }       // b is a compile-time constant after unrolling
+                }
                 xr[j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
+            }
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             float s = 0.f;
