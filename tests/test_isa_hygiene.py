@@ -82,6 +82,19 @@ def test_gemv_weight_stream_is_issued_before_any_drain(kernels):
         assert not drains, (n, drains)
 
 
+def test_weight_stream_goes_out_early(kernels):
+    """The epilogue's address arithmetic (two integer divisions per row for the KV append) sits BEHIND the weight issue, and a
+    kernel that reads its input straight from global memory (fc2, multi-row out_proj) loads it IN FRONT of the weights."""
+    for n, b in select(kernels, r"gemv_kernelI(f|DF16_)Li1ELi1ELi[12]ELi[12]ELi3ELi\d+EEE").items():      # qkv, one row
+        w = [i for i, l in enumerate(b) if l.startswith("global_load_dwordx4") and l.endswith(" nt")]
+        assert w[-1] < 140, (n, w[-1], "weight loads delayed by epilogue arithmetic")
+        assert not count(b[:w[0]], "v_rcp_iflag"), (n, "integer division in front of the weight stream")
+    for n, b in select(kernels, r"gemv_kernelI(f|DF16_)Li4ELi1ELi2ELi0ELi2ELi4EEE").items():               # fc2, one row
+        w = [i for i, l in enumerate(b) if l.startswith("global_load_dwordx4") and l.endswith(" nt")]
+        x = [i for i, l in enumerate(b) if l.startswith("global_load_dwordx4") and not l.endswith(" nt")]
+        assert x and max(x) < min(w), (n, "input slice loads must precede the weight loads")
+
+
 def test_qkv_position_word_is_a_vector_load(kernels):
     """pos[b] of the KV-append epilogue must not be a scalar load: scalar loads share lgkmcnt with LDS, and the wait in front of
     the LayerNorm prologue's first barrier then sits out its memory round trip."""
