@@ -14,7 +14,10 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "er_api.hip")
 LIB = os.path.join(PKG, "libedgerunner_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", "-shared", "-fPIC"]
+# -amdgpu-kernarg-preload-count: leading SCALAR kernel arguments arrive in SGPRs at wave launch (the single-row decode kernels lead
+# their argument lists with the pointers their first loads need: csrc/k_gemv.h)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+         "-shared", "-fPIC"]
 
 
 def sources():

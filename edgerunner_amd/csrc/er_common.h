@@ -4,6 +4,11 @@
 #include <stdint.h>
 #include <math.h>
 
+// gfx950 only: v_permlane32/16_swap, global_load_lds_dwordx4, 160 KB LDS per CU (k_gemm.h's 128 x 128 fp32 tile holds 66.8 KB)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "edgerunner_hip is written for gfx950 (MI355X): build with --offload-arch=gfx950 (edgerunner_amd/build.py)"
+#endif
+
 #define ER_WAVE 64
 #define ER_WG 256          // threads per workgroup used by every kernel here
 #define ER_NWAVES 4        // ER_WG / ER_WAVE

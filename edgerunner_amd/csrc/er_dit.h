@@ -400,7 +400,9 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         HIPCHK(hipMemcpy((void*)c->sst_ptrs, hp.data(), hp.size() * sizeof(float*), hipMemcpyHostToDevice));
     }
     // fp16 activations for the LDS-DMA GEMM (all K of this path are multiples of 64 except none: C = 1024, 4C = 4096)
-    const bool hh = flash && C % 64 == 0;
+    // ... and the LDS-DMA attention wants whole 64-row tiles of latent tokens and cross K / V^T prepared (zero-padded) for THIS
+    // condition length; any other shape keeps the fp32-operand fused attention + register-staged GEMMs below (x16 / att16 null)
+    const bool hh = flash && C % 64 == 0 && N % 64 == 0 && c->kv2_mp == (M + 63) / 64 * 64;
     if (hh) {
         ERCHK(ensure(c->x16, (size_t)R * C / 2 + 8));
         ERCHK(ensure(c->att16, (size_t)R * C / 2 + 8));
@@ -418,7 +420,6 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     _Float16* qkv16 = hh ? reinterpret_cast<_Float16*>(c->qkv16.p) : nullptr;
     _Float16* vt16 = hh ? reinterpret_cast<_Float16*>(c->vt16.p) : nullptr;
     _Float16* q2_16 = hh ? reinterpret_cast<_Float16*>(c->q2_16.p) : nullptr;
-    if (hh && (N % 64 != 0 || c->kv2_mp != (M + 63) / 64 * 64)) return fail(ER_ERR_INVALID, "dit: fp16 attention operands are not prepared (latent_size %% 64, cross K/V)");
     ERCHK(dit_time_embed(c, B, st));
     {
         const long long ng = (long long)g.num_layers * 2 * B * C;

@@ -517,8 +517,13 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
     ER_TP(7);
 }
 
+// Argument list: the length word's address, q, the cache and partial pointers and the two length integers lead as SCALARS (preloaded
+// into SGPRs at wave launch, see k_gemv.h gemv_kernel); the struct behind them supplies the rest, its copies of these fields are ignored.
 template <typename KT, int D, int STEPS, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(AttnDecArgs a) {
+__global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(const int* plen, const float* pq, const void* pk, const void* pv, float* ppart,
+                                                               float* ppml, int pfixed, int padd, AttnDecArgs a_) {
+    AttnDecArgs a = a_;
+    a.len_src = plen; a.q = pq; a.kcache = pk; a.vcache = pv; a.part = ppart; a.part_ml = ppml; a.fixed_len = pfixed; a.len_add = padd;
     constexpr int KPW = 64 / KVec<KT>::LPK;
     static_assert(NW == 16 && D % NW == 0 && D + 1 == A3_LD, "wave merge: the 4 * NW row partials of a column fill the 64 lanes of one wave");
     __shared__ __attribute__((aligned(16))) float ored[NW * 4 * A3_LD];
@@ -587,8 +592,10 @@ inline hipError_t launch_attn_partial3_d(const AttnDecArgs& a_in, bool kv_half, 
     // (with a fixed length and no length array the kernel's unconditional length load reads a word of the partials buffer and ignores it)
     a.len_src = a.len_dev ? a.len_dev : (a.pos ? a.pos : reinterpret_cast<const int*>(a.part_ml));
     a.len_add = a.len_dev ? 0 : 1;
-    if (!kv_half) hipLaunchKernelGGL((attn_decode3_kernel<float, D, 4, ATTN3_NW>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((attn_decode3_kernel<_Float16, D, 2, ATTN3_NW>), grid, blk, 0, st, a);
+    if (!kv_half) hipLaunchKernelGGL((attn_decode3_kernel<float, D, 4, ATTN3_NW>), grid, blk, 0, st, a.len_src, a.q, a.kcache, a.vcache, a.part,
+                                     a.part_ml, a.fixed_len, a.len_add, a);
+    else hipLaunchKernelGGL((attn_decode3_kernel<_Float16, D, 2, ATTN3_NW>), grid, blk, 0, st, a.len_src, a.q, a.kcache, a.vcache, a.part,
+                            a.part_ml, a.fixed_len, a.len_add, a);
     return hipGetLastError();
 }
 

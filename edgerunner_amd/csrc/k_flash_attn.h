@@ -278,10 +278,13 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
         const int kbase = t * FA_KT, cur = t & (NST - 1);
         // tile t has landed when at most the pieces of the tiles issued after it (4 per tile and wave) are outstanding
         const int ahead = min(NST - 2, ntiles - 1 - t);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // everybody's pieces of tile t are in LDS; everybody is done reading tile t - 1
+        // wait and barrier in ONE statement: the s_barrier builtin carries no fence, so nothing else would keep a compiler-scheduled
+        // fragment read from moving between the counted wait and the barrier.  (The counts assume the loop issues no other VMEM
+        // operation - no scratch: tests/test_isa_hygiene.py checks the kernel for both.)
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // everybody's pieces of tile t are in LDS; everybody is done reading tile t - 1
         if (t + NST - 1 < ntiles) issue(t + NST - 1, (t + NST - 1) & (NST - 1));      // into the stage tile t - 1 just vacated
         const _Float16* Ks = lds + cur * 2 * TILE;
         const _Float16* Vs = Ks + TILE;

@@ -146,8 +146,17 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int n, int b, f
 // NW = waves per workgroup.  The grid should be a whole number of workgroups per CU (256 CUs): 4608 qkv rows are 768
 // workgroups of 3 waves x 2 rows (3 per CU) - with 4-wave workgroups they are 1152 (4.5 per CU: the CUs that get 5 set
 // the kernel's time) - and the 1536 out_proj rows are 512 workgroups of 3 waves x 1 row.
+//
+// Kernel arguments: the seven pointers the FIRST loads of a wave need lead the argument list as scalars, the struct follows.  With
+// `-mllvm -amdgpu-kernarg-preload-count` (edgerunner_amd/build.py) the firmware hands leading scalar arguments to every wave in SGPRs
+// at launch, so the input / LayerNorm / bias / position loads and the weight stream go out without first waiting for an s_load of the
+// argument block (a struct passed by value is never preloaded; measured on the plain-kernel chain: -0.09 us per launch,
+// profiles/r03_kernarg_preload_probe.log).  The same fields inside the struct are ignored.
 template <typename WT, int KS, int NB, int RW, int PRO, int EPI, int NW = ER_NWAVES>
-__global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
+__global__ __launch_bounds__(64 * NW) void gemv_kernel(const void* pW, const float* pxin, const float* pln_w, const float* pln_b,
+                                                       const float* pbias, const float* presid, const int* ppos, GemvArgs a_) {
+    GemvArgs a = a_;
+    a.W = pW; a.xin = pxin; a.ln_w = pln_w; a.ln_b = pln_b; a.bias = pbias; a.resid = presid; a.pos = ppos;
     constexpr int TPB = 64 * NW;
     constexpr int EPL = WTraits<WT>::EPL, XV = EPL / 4, SL = 1536, J = SL / (64 * EPL);
     constexpr int K = KS * SL;
@@ -201,17 +210,10 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
         const int t = min(tid, RW * NB - 1);
         pre[0][0] = gemv_epi_loads<EPI>(a, row0 + t / NB, t % NB);
     }
-    // PRO_NONE reads its input straight from global memory: the first batch row's slice goes out IN FRONT of the weight stream like
-    // every other small operand (read in the main loop it queued behind the weights, and hipcc then interleaved the six loads with
-    // the first FMAs - a chain of L2 round trips AFTER the last weight byte had landed; fc2 and the out_proj of 2..8 rows)
-    f32x4 x0[PRO == PRO_NONE ? J * XV : 1];
-    if constexpr (PRO == PRO_NONE) {
-        const float* xsrc = a.xin + slice * SL;
-#pragma unroll
-        for (int j = 0; j < J; ++j)
-#pragma unroll
-            for (int u = 0; u < XV; ++u) x0[j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
-    }
+    // (Round 3 shipped, unmeasured, a variant that loaded PRO_NONE's input slice HERE, in front of the weight stream; measured in
+    // round 4 it made fc2 SLOWER - 8.10 vs 7.97 us, profiles/r04_ab_b5b758c_and_om_rpw.log - the six extra 16-byte loads per lane delay
+    // the first weight request of every wave by more than the L2 round trip they take off the tail.  The input is read in the main
+    // loop again.)
     f32x4 w[RW][J];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -295,12 +297,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_kernel(GemvArgs a) {
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
-            for (int u = 0; u < XV; ++u) {
-                if constexpr (PRO == PRO_NONE) {
-                    if (b == 0) { xr[j * XV + u] = x0[j * XV + u]; continue; }       // b is a compile-time constant after unrolling
-                }
-                xr[j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
-            }
+            for (int u = 0; u < XV; ++u) xr[j * XV + u] = reinterpret_cast<const f32x4*>(xsrc)[(j * 64 + lane) * XV + u];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             float s = 0.f;
@@ -344,7 +341,8 @@ inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t st) {
     const int rows_per_block = (KS == 1) ? NW * RW : RW;
     const int grid = (a.N + rows_per_block - 1) / rows_per_block;
     const size_t lds = (size_t)((PRO == PRO_NONE ? 0 : NB * K) + 64) * sizeof(float);
-    hipLaunchKernelGGL((gemv_kernel<WT, KS, NB, RW, PRO, EPI, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((gemv_kernel<WT, KS, NB, RW, PRO, EPI, NW>), dim3(grid), dim3(64 * NW), lds, st, a.W, a.xin, a.ln_w, a.ln_b, a.bias, a.resid,
+                       a.pos, a);
     return hipGetLastError();
 }
 

@@ -33,8 +33,13 @@ struct OutMergeArgs {
 
 constexpr int OM_WAVES = 8, OM_ROWS = 6, OM_THREADS = OM_WAVES * 64;
 
+// All seven arguments are scalars (13 dwords): preloaded into SGPRs at wave launch (k_gemv.h gemv_kernel), so the partial / weight
+// loads do not wait for an s_load of the argument block.
 template <typename WT, int D, int NCH>
-__global__ __launch_bounds__(OM_THREADS) void outproj_merge_kernel(OutMergeArgs a) {
+__global__ __launch_bounds__(OM_THREADS) void outproj_merge_kernel(const void* pW, const float* pbias, const float* presid, const float* ppart_o,
+                                                                   const float* ppart_ml, float* pout, int pN) {
+    OutMergeArgs a;
+    a.W = pW; a.bias = pbias; a.resid = presid; a.part_o = ppart_o; a.part_ml = ppart_ml; a.out = pout; a.N = pN;
     constexpr int EPL = WTraits<WT>::EPL, XV = EPL / 4, K = 1536, J = K / (64 * EPL);
     constexpr int C4 = D / 4;                 // float4 columns per head (24)
     static_assert(D == 96 && NCH <= 32 && C4 <= 32 && K == 16 * D, "two 96-wide heads per wave, 16 heads");
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(OM_THREADS) void outproj_merge_kernel(OutMergeArgs 
 template <typename WT, int D>
 inline hipError_t launch_outproj_merge(const OutMergeArgs& a, int nch, hipStream_t st) {
     const int grid = a.N / OM_ROWS;            // 1536 / 6 = 256: one workgroup per CU
-    if (nch == 16) hipLaunchKernelGGL((outproj_merge_kernel<WT, D, 16>), dim3(grid), dim3(OM_THREADS), 0, st, a);
+    if (nch == 16) hipLaunchKernelGGL((outproj_merge_kernel<WT, D, 16>), dim3(grid), dim3(OM_THREADS), 0, st, a.W, a.bias, a.resid, a.part_o, a.part_ml,
+                                      a.out, a.N);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -115,6 +115,14 @@ def save_ply(path: str, vertices: np.ndarray, faces: np.ndarray) -> None:
             fh.write(f"3 {int(f[0])} {int(f[1])} {int(f[2])}\n")
 
 
+def save_obj(path: str, vertices: np.ndarray, faces: np.ndarray) -> None:
+    with open(path, "w") as fh:
+        for v in vertices:
+            fh.write(f"v {v[0]:.8f} {v[1]:.8f} {v[2]:.8f}\n")
+        for f in faces:
+            fh.write(f"f {int(f[0]) + 1} {int(f[1]) + 1} {int(f[2]) + 1}\n")
+
+
 def save_points_obj(path: str, points: np.ndarray) -> None:
     with open(path, "w") as fh:
         for p in points:

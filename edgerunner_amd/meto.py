@@ -122,13 +122,16 @@ def detokenize_mesh(tokens, discrete_bins: Optional[int] = None, tokenizer: Opti
 # save_mesh's clean-up (core/provider.py:52-58):
 #     mesh = trimesh.Trimesh(vertices, faces)      # process=True: merge_vertices on construction
 #     mesh.merge_vertices(); mesh.update_faces(mesh.unique_faces()); mesh.fix_normals()
-# trimesh is a third-party dependency that is absent from /root/reference and from this image (requirements.txt:
-# `trimesh`, unpinned), so the three calls are RESTATED here from trimesh's published algorithms (4.x: grouping.py
-# merge_vertices, base.py unique_faces, repair.py fix_winding / fix_inversion) - parity unpinned: there is no executable
-# trimesh to check against; the tests pin the properties the calls guarantee.  What is and is not reproduced:
+# trimesh is a third-party dependency that is absent from /root/reference and from this image (pinned
+# `trimesh == 4.0.5`, requirements.lock.txt:32), so the three calls are RESTATED here from that version's published
+# algorithms (grouping.py merge_vertices, base.py unique_faces, repair.py fix_winding / fix_inversion) - parity unpinned:
+# there is no executable trimesh to check against; the tests pin the properties the calls guarantee.  What is and is not
+# reproduced:
 #   * merge_vertices: referenced vertices whose coordinates agree after rounding to 8 decimals (tol.merge = 1e-8) become
-#     one vertex, unreferenced vertices are dropped.  trimesh orders the surviving vertices by the sort order of a row
-#     hash; here they are ordered lexicographically - same SET of vertices, same faces up to that relabelling.
+#     one vertex, unreferenced vertices are dropped.  trimesh 4.0.5 finds the groups with
+#     `unique_rows(stacked[referenced], keep_order=True)` (grouping.unique_ordered: np.unique, then the groups re-ordered by
+#     the index of their FIRST member), so the surviving vertices keep the order of their first occurrence - restated
+#     exactly so (rounds 1-3 ordered them lexicographically, which is what np.unique alone would give).
 #   * unique_faces: of faces that use the same three vertices (in any order / winding) the first is kept.  Degenerate
 #     faces (a repeated vertex) are KEPT, as trimesh keeps them (only Trimesh(validate=True) drops them).
 #   * fix_normals = fix_winding + fix_inversion: inside every edge-connected component (edges shared by exactly two
@@ -145,9 +148,12 @@ def merge_vertices(vertices: np.ndarray, faces: np.ndarray, digits: int = 8):
     keys = np.round(vertices * (10.0 ** digits)).astype(np.int64)
     ref_idx = np.nonzero(referenced)[0]
     _, first, inv = np.unique(keys[ref_idx], axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")           # groups in the order of their first member (trimesh unique_ordered)
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
     inverse = np.zeros(len(vertices), dtype=np.int64)
-    inverse[ref_idx] = inv.reshape(-1)
-    return vertices[ref_idx[first]], inverse[faces]
+    inverse[ref_idx] = rank[inv.reshape(-1)]
+    return vertices[ref_idx[first[order]]], inverse[faces]
 
 
 def unique_faces_mask(faces: np.ndarray) -> np.ndarray:
@@ -271,8 +277,35 @@ def merge_and_dedupe(vertices: np.ndarray, faces: np.ndarray):
     return v, f[unique_faces_mask(f)]
 
 
+class Mesh:
+    """What ``LMM.generate`` / ``save_mesh`` hand back where the reference returns a ``trimesh.Trimesh``
+    (core/models.py:315-319, core/provider.py:48-66): ``.vertices`` [V,3] float64, ``.faces`` [F,3] int64 and
+    ``.export(path)`` (.ply / .obj) - the three members the reference's callers use (infer.py:120, infer_dit.py:126,
+    main.py:287 all call ``mesh.export(...)``).  It also unpacks like the ``(vertices, faces)`` pair earlier rounds
+    returned: ``v, f = mesh``."""
+
+    def __init__(self, vertices, faces):
+        self.vertices = np.asarray(vertices)
+        self.faces = np.asarray(faces)
+
+    def export(self, path: str):
+        from .meshio import save_obj, save_ply
+        (save_obj if str(path).lower().endswith(".obj") else save_ply)(str(path), self.vertices, self.faces)
+        return path
+
+    def __iter__(self):
+        yield self.vertices
+        yield self.faces
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        return (self.vertices, self.faces)[i]
+
+
 def save_mesh(tokens, opt, path=None, tokenizer=None, clean=True, verbose=False):
-    """core/provider.py:39-66: ids -> (vertices, faces) [-> .ply when path is given]."""
+    """core/provider.py:39-66: ids -> Mesh(vertices, faces) [-> written to ``path`` when given, like mesh.export(path) there]."""
     tokens = np.asarray(tokens)
     eos = np.nonzero(tokens == opt.eos_token_id)[0]
     if len(eos) > 0:
@@ -284,7 +317,7 @@ def save_mesh(tokens, opt, path=None, tokenizer=None, clean=True, verbose=False)
         vertices, faces = clean_like_trimesh(vertices, faces)
         if verbose:
             print(f"[INFO] cleaned vertices: {vertices.shape[0]}, faces: {faces.shape[0]}")
+    mesh = Mesh(vertices, faces)
     if path is not None:
-        from .meshio import save_ply
-        save_ply(path, vertices, faces)
-    return vertices, faces
+        mesh.export(path)
+    return mesh

@@ -52,6 +52,15 @@ class LMM:
         if opt.cond_mode == "point" and opt.point_encoder_mode != "embed":
             raise NotImplementedError("point_encoder_mode='downsample' needs torch_cluster FPS; ArAE uses 'embed'")
         self.dims = dims_from_options(opt)
+        if (self.dims.hidden_dim, self.dims.intermediate_dim) != (1536, 6144) or self.dims.hidden_dim // max(self.dims.num_heads, 1) not in (96, 64):
+            # the decode kernels stream 1536-wide rows in whole 1536-element slices (csrc/k_gemv.h); the reference's generic
+            # ShapeOPTConfig (core/transformer/modeling_opt.py:86-134; Options() default hidden_dim 1024) is not built - say so
+            # here, with the option names, instead of from er_create
+            raise NotImplementedError(
+                f"decoder shape hidden_dim={self.dims.hidden_dim} / intermediate_dim={self.dims.intermediate_dim} / "
+                f"num_heads={self.dims.num_heads} is not built: this library serves the ArAE / DiT presets' decoder "
+                "(hidden_dim=1536, intermediate_dim=6144, head_dim 96 or 64). Use config_defaults['ArAE'] (or 'DiT'), "
+                "or pass --hidden_dim 1536 --num_heads 16 --intermediate_dim 6144.")
         self.vocab_size = self.dims.vocab_size
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -60,6 +69,7 @@ class LMM:
         self._dec: Optional[NativeShapeOPT] = None
         self._sources: List[tuple] = []        # (state_dict reference, strict) of every load_state_dict call, for re-creation
         self.training = False
+        self._released = False                 # release_checkpoint() was called: the context cannot be re-created
         if precision is not None:
             self._materialize()
 
@@ -69,6 +79,9 @@ class LMM:
         return "fp16" if self._dtype == torch.float16 else "fp32"
 
     def _materialize(self):
+        if self._released:
+            raise native.NativeError("LMM: the checkpoint was released (release_checkpoint()) and the native context is gone; "
+                                     "create a new LMM and load the checkpoint again")
         dec = NativeShapeOPT(self.dims, self.opt, self.device, weight_dtype=self._dtype, kv_dtype=self._dtype)
         dec.model = _DecoderModel(dec)
         for sd, strict in self._sources:
@@ -106,6 +119,7 @@ class LMM:
         _ = self.mesh_decoder                  # make sure everything retained so far is on the device
         self._sources.clear()
         self._dec.direct_loads = True
+        self._released = True
         return self
 
     def _cast(self, dtype):
@@ -190,7 +204,8 @@ class LMM:
                  min_new_tokens: int = 0, seed: Optional[int] = None, row_streams=None):
         """-> (meshes, all_tokens) like core/models.py:204-319.  ``tokenizer`` is a
         ``edgerunner_amd.meto.Engine`` (or None for the 9-coordinate layout); each mesh is a
-        ``(vertices, faces)`` pair (the reference returns trimesh objects, absent here)."""
+        ``edgerunner_amd.meto.Mesh`` - ``.vertices``, ``.faces``, ``.export(path)``, the members the reference's callers
+        use of the trimesh objects it returns (trimesh itself is absent here); it still unpacks as ``v, f = mesh``."""
         output_ids = self.generate_ids(conds, num_faces, resume_ids, tokenizer, max_new_tokens, min_new_tokens, seed, row_streams)
         from .meto import Engine, save_mesh
         meshes: List[Optional[object]] = []
@@ -200,7 +215,7 @@ class LMM:
             tokens = out[b]
             if resume_ids is not None:
                 tokens = np.concatenate((resume_ids[b].detach().cpu().numpy(), tokens), axis=0)
-            # batch detokenize (core/models.py:315): (vertices, faces) instead of a trimesh object
+            # batch detokenize (core/models.py:315): a meto.Mesh instead of a trimesh object
             if tokenizer is None or isinstance(tokenizer, Engine):
                 meshes.append(save_mesh(tokens, self.opt, tokenizer=tokenizer, clean=clean))
             else:

@@ -58,6 +58,10 @@ class MDiT:
         return "fp16" if self._fp16 else "fp32"
 
     def _materialize(self):
+        if self._released and not self._sources:
+            # close() after release_checkpoint(): the weights lived only in the native context that was just destroyed
+            raise native.NativeError("MDiT: the native context was closed after release_checkpoint(); the checkpoint is gone - "
+                                     "create a new MDiT and load the checkpoint again")
         opt = self.opt
         cfg = native.ErDitConfig(hidden_dim=opt.dit_hidden_dim, num_heads=opt.dit_num_heads, num_layers=opt.dit_num_layers,
                                  latent_size=opt.point_latent_size, latent_dim=opt.point_latent_dim, clip_dim=CLIP_DIM,

@@ -12,7 +12,9 @@ import os
 from typing import Optional, Sequence
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libedgerunner_hip.so")
+# ER_LIB_PATH: A/B handle of the measurement scripts (another BUILD of the same library, e.g. build/ab/*.so); a path that
+# does not exist fails as loudly as a missing default build
+LIB_PATH = os.environ.get("ER_LIB_PATH") or os.path.join(PKG, "libedgerunner_hip.so")
 
 ER_F32, ER_F16, ER_BF16 = 0, 1, 2
 ER_COND_NONE, ER_COND_POINT, ER_COND_POINT_LATENT = 0, 1, 2

@@ -7,6 +7,11 @@
 Same flags (``edgerunner_amd.options`` mirrors ``core/options.py``), same outputs
 (``{name}_{i}_{n}f_tokens.npy`` = ids-3 cut at EOS, ``{name}_pc.obj``; reference infer.py:86-123).
 Inputs: .obj/.ply meshes (surface-sampled to ``point_num`` points) or .npy point clouds [N,3].
+Difference from the reference on MESH inputs: reference infer.py:86 first runs ``kiui.mesh_utils.clean_mesh(v, f, min_f=0, min_d=0,
+remesh=False)`` (pymeshlab filters - both packages absent here and not restated) and samples with ``trimesh.sample``; this script
+normalises the mesh as loaded and uses its own seeded area-weighted sampler, so the conditioning cloud is a different sample of the
+same surface.  ``.npy`` clouds are passed through untouched (identical conditions for both code bases).  Meshes are written with
+``mesh.export(...)`` on the ``edgerunner_amd.meto.Mesh`` objects generate() returns (reference infer.py:120 on trimesh objects).
 ``--cond_mode none`` (reference infer.py:96-97) generates from the face-count token alone, once per input path.
 With torchrun (one process per GPU) the (file x repeat x num_face) jobs are sharded block-cyclically over ranks;
 inside a rank, jobs with the same face count run as ONE batched generate() call (the B > 1 decode path streams the
@@ -147,7 +152,7 @@ def main(argv=None):
             filename = f"{name}_{i}" + (f"_{num_faces}f" if opt.use_num_face_cond else "")
             np.save(f"{opt.workspace}/{filename}_tokens.npy", toks)
             if meshes[r] is not None:
-                meshio.save_ply(f"{opt.workspace}/{filename}.ply", meshes[r][0], meshes[r][1])
+                meshes[r].export(f"{opt.workspace}/{filename}.ply")               # reference infer.py:120
             local_streams[j] = toks
             print(f"[INFO] Processing {path} --> {filename}.ply, {len(toks)} tokens, time = {dt:.4f}s "
                   f"({len(chunk)} jobs in this call)")

@@ -108,7 +108,7 @@ def main(argv=None):
         filename = f"{name}_{i}" + (f"_{num_faces}f" if opt.use_num_face_cond else "")
         np.save(f"{opt.workspace}/{filename}_tokens.npy", tokens)
         if meshes[0] is not None:
-            meshio.save_ply(f"{opt.workspace}/{filename}.ply", meshes[0][0], meshes[0][1])
+            meshes[0].export(f"{opt.workspace}/{filename}.ply")                   # reference infer_dit.py:126
         torch.cuda.synchronize()
         print(f"[INFO] Processing {path} --> {filename}, {len(tokens)} tokens, time = {time.time() - t0:.4f}s")
     D.barrier()

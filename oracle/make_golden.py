@@ -12,6 +12,7 @@ Usage:  python oracle/make_golden.py small|eos  # ~1 min each
         python oracle/make_golden.py dit_full   # ~5 min (24 DiT + 32 CLIP layers, 3 DDIM steps)
         python oracle/make_golden.py batch      # ~6 min (24 layers, 3 rows x 3 modes x 48 steps)
         python oracle/make_golden.py long       # ~10 min, ~40 GB RAM (2 layers, 12000 resumed tokens: decode from context 14050)
+        python oracle/make_golden.py long24     # ~1.5 h, ~40 GB RAM (24 layers: fp32 at context 14050, fp16 emulation at 18050)
 Fixtures are small .npz files; the weights are regenerated from the seed by
 ``edgerunner_amd.weights`` (never committed).
 """
@@ -406,6 +407,53 @@ def make_long(R=12000, T=40):
 
 
 @torch.no_grad()
+def make_long24(R=12000, T=16, R2=16000, T2=8):
+    """Full-DEPTH long-context goldens, one cloud each:
+      (a) the reference's own modules at 24 layers, fp32, R = 12000 resumed tokens (prefix 14050 positions), T greedy steps with
+          their logits - the single-row fallback for reserved caches > 8192 keys, the B = 6 split path and the B = 18 streaming
+          path are checked against it on the GPU;
+      (b) BASELINE configs[2]'s shape at its REAL context: fp16-storage emulation (oracle restatement, which (a)'s sibling
+          goldens pin to the reference modules), face bucket 3, R2 = 16000 resumed tokens -> contexts 18050 .. 18050 + T2,
+          greedy ids + logits for a teacher-forced pass through the batched streaming kernel.  The naive score matrices of
+          this one (16 x 18050^2 fp32) are produced four heads at a time (arae_oracle.HEAD_CHUNK; same arithmetic per head)."""
+    import zlib
+    opt, ref_opt = opts(24, generate_mode="greedy")
+    sd = W.make_state_dict(opt, WEIGHT_SEED, WEIGHT_STYLE)
+    out = {"T": np.array([T]), "R": np.array([R]), "T2": np.array([T2]), "R2": np.array([R2]), "row": np.array([0])}
+    t0 = time.time()
+    model = build_reference(ref_opt, sd)
+    pc = W.synthetic_point_cloud(0, 4096)
+    resume = W.synthetic_resume_ids(500, R)
+    i, l = run_case(model, sd, opt, pc, 4000, T, T, resume_ids=torch.from_numpy(resume)[None], n_logits=T,
+                    check_restatement=False)
+    out.update(ids=i[0], logits=l[:, 0], resume_crc32=np.array([zlib.crc32(resume.astype(np.int64).tobytes())], dtype=np.int64))
+    print(f"(a) fp32 reference modules, context {2050 + R}: {time.time() - t0:.0f}s  ids {i[0]}", flush=True)
+    del model
+    sd16 = O.round_streamed_weights(sd, torch.float16)
+    fwd16 = O.make_forward(sd16, opt, kv_round=torch.float16)
+    O.HEAD_CHUNK = 4
+    resume2 = W.synthetic_resume_ids(900, R2)
+    rec = {}
+    i16 = O.lmm_generate_ids(sd16, opt, pc, 4000, resume_ids=torch.from_numpy(resume2)[None], max_new_tokens=T2,
+                             min_new_tokens=T2, fwd=fwd16,
+                             record_logits=lambda t, s_: rec.__setitem__(t, s_.numpy()[0].copy()))
+    O.HEAD_CHUNK = 0
+    out.update(ids_fp16=i16.numpy()[0], logits_fp16=np.stack([rec[t] for t in range(T2)]),
+               resume2_crc32=np.array([zlib.crc32(resume2.astype(np.int64).tobytes())], dtype=np.int64))
+    print(f"(b) fp16 emulation, context {2050 + R2}: {time.time() - t0:.0f}s  ids {i16.numpy()[0]}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, "arae_long24.npz"), **out)
+    manifest_update("arae_long24", {"num_layers": 24, "row": 0, "num_faces": 4000,
+                                    "fp32": {"T": T, "resume_tokens": R, "context": [2050 + R, 2050 + R + T],
+                                             "resume": "edgerunner_amd.weights.synthetic_resume_ids(500, R)",
+                                             "source": "reference modules under the restated loop"},
+                                    "fp16": {"T": T2, "resume_tokens": R2, "context": [2050 + R2, 2050 + R2 + T2],
+                                             "resume": "edgerunner_amd.weights.synthetic_resume_ids(900, R2)",
+                                             "source": "oracle restatement, fp16-rounded streamed weights + fp16-rounded K/V"},
+                                    "cases": {k: list(v.shape) for k, v in out.items()}})
+    print({k: v.shape for k, v in out.items()})
+
+
+@torch.no_grad()
 def make_dit_full(steps=3):
     """BASELINE configs[4] at FULL depth: the reference's own DiT module with 24 layers, fed by the 32-layer CLIP ViT-H/14
     restatement (checked against the installed transformers CLIPVisionModel at 2 layers in make_dit), a `steps`-step
@@ -456,5 +504,7 @@ if __name__ == "__main__":
         make_dit_full()
     elif what == "long":
         make_long()
+    elif what == "long24":
+        make_long24()
     else:
         raise SystemExit(__doc__)

@@ -179,6 +179,34 @@ def test_fast_mode_fp16_mfma_vs_emulation(setup):
     assert e_cond < 2e-3 and e_lat < 1e-2 and drift < 5e-2
 
 
+def test_fast_mode_fp16_latent_size_not_a_multiple_of_64():
+    """fp16 mode with a latent size that is not a whole number of 64-token tiles (point_latent_size = 100): the LDS-DMA
+    GEMM / attention pair does not apply, the context must fall back to the fp32-operand fused attention + register-staged
+    fp16 GEMMs (round-3 advisor: that shape returned ER_ERR_INVALID) and still match the fp16 emulation."""
+    import arae_oracle as O
+    from edgerunner_amd import weights as W
+    from edgerunner_amd.models_dit import MDiT
+    from edgerunner_amd.options import config_defaults
+    opt = dataclasses.replace(config_defaults["ArAE"], num_layers=2, generate_mode="greedy", cond_mode="point_latent",
+                              dit_num_layers=2, point_latent_size=100)
+    sd = W.make_dit_state_dict(opt, 3, "perturbed")
+    m = MDiT(opt, DEV, clip_layers=0, precision="fp16")
+    m.load_state_dict(sd, strict=True)
+    gen = torch.Generator().manual_seed(77)
+    clip_hidden = torch.randn(2, 257, 1280, generator=gen)
+    x = torch.randn(2, 100, 64, generator=gen)
+    t = torch.tensor([801.0, 41.0])
+    sd_h = O.round_linear_weights(sd)
+    with O.linear_input_rounding(torch.float16):
+        cond_w = O.dit_project_cond(sd_h, clip_hidden)
+        want = O.dit_forward(sd_h, x, cond_w, t, opt.dit_num_heads)
+    cond = m.get_cond(clip_hidden.to(DEV))
+    got = m.dit(x.to(DEV), cond, t)
+    err = float((got.cpu() - want).abs().max())
+    print(f"fp16 DiT forward, latent_size 100: max err vs fp16 emulation {err:.3e}")
+    assert err < 5e-3
+
+
 def test_full_depth_24_dit_32_clip_layers_vs_reference_golden():
     """BASELINE configs[4] at FULL depth: image -> CLIP ViT-H/14 (32 layers) -> proj/norm -> DiT (24
     layers) under CFG 7.5 / DDIM, 3 steps, exact fp32, against tests/golden/dit_full.npz (the reference's own DiT module

@@ -200,7 +200,27 @@ def test_clean_like_trimesh_merge_unique_and_winding():
     iv, if_ = meto.clean_like_trimesh(v, f[:, ::-1])
     assert _signed_volume(iv, if_) == pytest.approx(1.0)
     kv, kf = meto.clean_like_trimesh(v, f)
-    assert np.array_equal(kv, v[np.lexsort((v[:, 2], v[:, 1], v[:, 0]))]) and _signed_volume(kv, kf) == pytest.approx(1.0)
+    assert np.array_equal(kv, v) and np.array_equal(kf, f) and _signed_volume(kv, kf) == pytest.approx(1.0)    # vertex ORDER kept too
+    # merged vertices keep the order of their first occurrence (trimesh 4.0.5 unique_rows(..., keep_order=True)), not a sorted one
+    pv = np.array([[3.0, 0, 0], [1.0, 0, 0], [9.0, 9, 9], [2.0, 0, 0], [1.0, 0, 0], [3.0, 0, 0], [0.5, 1, 0]])
+    pf = np.array([[0, 1, 3], [4, 5, 6]])
+    mv, mf = meto.merge_vertices(pv, pf)
+    assert mv.tolist() == [[3.0, 0, 0], [1.0, 0, 0], [2.0, 0, 0], [0.5, 1, 0]] and mf.tolist() == [[0, 1, 2], [1, 0, 3]]
+
+
+def test_mesh_object_exports_like_the_reference_callers_expect(tmp_path):
+    """LMM.generate returns objects with .vertices / .faces / .export(path) (what infer.py:120 uses of trimesh.Trimesh);
+    they still unpack as (vertices, faces)."""
+    from edgerunner_amd import meshio, meto
+    v, f = _cube()
+    m = meto.Mesh(v, f)
+    vv, ff = m
+    assert vv is m.vertices and ff is m.faces and m[0] is m.vertices and len(m) == 2
+    for ext in ("ply", "obj"):
+        path = str(tmp_path / f"cube.{ext}")
+        assert m.export(path) == path
+        rv, rf = meshio.load_mesh(path)
+        assert np.allclose(rv, v, atol=1e-6) and np.array_equal(rf, f)
 
 
 def test_clean_like_trimesh_multibody_and_reference_fixtures():
