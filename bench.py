@@ -277,26 +277,35 @@ def dry_run(args):
     B, T = args.batch_per_gpu, args.tokens or 4 * args.num_face
     n_items = world * B
 
+    gather_ms = []
+
     def one_step(k):
         mine = D.shard_indices(n_items, rank, world)
         streams = [np.full(T, 6 + (i + k) % 500, dtype=np.int64) for i in mine]
+        tg = time.perf_counter()
         got = D.gather_token_streams(streams, n_items)
+        gather_ms.append((time.perf_counter() - tg) * 1e3)
         assert len(got) == n_items and all(int(g[0]) == 6 + (i + k) % 500 for i, g in enumerate(got))
 
     for w in range(args.warmup):
         one_step(-1 - w)
+    gather_ms.clear()
     D.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k)
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(my_elapsed)
+    rk_wall, rk_gather = D.all_ranks(my_elapsed), D.all_ranks(float(np.mean(gather_ms)) if gather_ms else 0.0)
+    per_rank = {"wall_s": {"min": round(min(rk_wall), 4), "max": round(max(rk_wall), 4)},
+                "gather_ms_per_step": {"min": round(min(rk_gather), 3), "max": round(max(rk_gather), 3)}, "ranks_reporting": len(rk_wall)}
     if rank == 0:
         print(json.dumps({"metric": "mesh tokens/sec (whole node), ArAE greedy test_num_face=1000", "dry_run": True,
                           "value": round(world * B * T * args.steps / max(elapsed, 1e-9), 2), "unit": "tokens/s",
                           "n_gpus": world, "world_size_seen": world, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "data": "fabricated (dry run: no GPU work)",
+                          "scaling": "weak", "vs_baseline": None, "data": "fabricated (dry run: no GPU work)", "per_rank": per_rank,
                           "config": {"workload": f"dry run: {B} fabricated stream(s) of {T} ids per rank", "batch_per_gpu": B}}))
     if world > 1:
         import torch.distributed as dist
@@ -353,7 +362,10 @@ def main(argv=None):
         pcs = torch.cat([W.synthetic_point_cloud(step_idx * n_items + i, args.points) for i in mine]).to(dev)   # resident in HBM
         _, toks = lmm.generate(pcs, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T, resume_ids=resume,
                                seed=(1000 + step_idx) if args.mode == "sample" else None)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
         streams = D.gather_token_streams([t[args.resume_len:] for t in toks], n_items, device=dev)
+        gather_ms.append((time.perf_counter() - tg) * 1e3)
         assert len(streams) == n_items and all(len(s) == T for s in streams)
         return lmm.mesh_decoder.last_decode_ms
 
@@ -361,17 +373,29 @@ def main(argv=None):
         if rank == 0:
             print(f"[bench +{time.time() - t0:.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    gather_ms = []
     for w in range(args.warmup):
         one_step(-1 - w)
     log("warmup done")
+    gather_ms.clear()
     D.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     dec_ms = [one_step(k) for k in range(args.steps)]
     torch.cuda.synchronize()
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t_start, dev)
+    my_elapsed = time.perf_counter() - t_start
+    elapsed = D.max_over_ranks(my_elapsed, dev)
     log(f"timed region done: {elapsed:.2f}s")
+    # what a first N > 1 run needs to explain itself: every rank's own wall time, decode rate and gather time (rank order)
+    rk_wall = D.all_ranks(my_elapsed, dev)
+    rk_dec = D.all_ranks(B * T / (float(np.mean(dec_ms)) / 1e3), dev)
+    rk_gather = D.all_ranks(float(np.mean(gather_ms)) if gather_ms else 0.0, dev)
+    per_rank = {"wall_s": {"min": round(min(rk_wall), 3), "max": round(max(rk_wall), 3)},
+                "decode_tokens_per_s": {"min": round(min(rk_dec), 1), "max": round(max(rk_dec), 1), "by_rank": [round(v, 1) for v in rk_dec]},
+                "gather_ms_per_step": {"min": round(min(rk_gather), 3), "max": round(max(rk_gather), 3),
+                                       "what": "host wall of the token-stream all-gather (one all-reduce of the width + one all-gather), "
+                                               "after the rank's own decode has drained; includes waiting for the slowest rank"}}
 
     total_tokens = n_items * args.steps * T
     value = total_tokens / elapsed
@@ -445,6 +469,7 @@ def main(argv=None):
                    "batch_per_gpu": B, "generate_mode": args.mode, "precision": args.precision,
                    "parallelism": f"dp{world} (independent samples, full replica per GPU)"},
         "decode_only_tokens_per_s": round(decode_only, 2),
+        "per_rank": per_rank,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and args.config == 1 and not args.overridden and not args.no_fast_extra:

@@ -113,6 +113,9 @@ struct er_ctx {
     bool batched = false;     // B > 4 (or ER_FORCE_BATCHED=1): weights streamed once per pass of 32 rows (matrix cores)
     bool batched_valu = false;   // ER_BATCHED_VALU=1: the older VALU kernels (one pass per 16 rows), kept for A/B runs
     float* skpart = nullptr;  // split-K partials of the batched fc2
+    // fast-mode batches on the matrix cores: activations in the tiled hi | lo operand layout (k_gemv.h xt_entry), one image per producer
+    void *xt_h = nullptr, *xt_att = nullptr, *xt_f = nullptr;     // LayerNorm rows (qkv / fc1 input), attention output, fc1 output
+    bool xt = false;          // ER_XT=0 keeps the row-major fp32 inputs (A/B + parity matrix)
     bool tiled_valid = false; // LayerW::*_t match the loaded weights
     // waves per workgroup of the qkv / fc1 GEMVs (env ER_NW_QKV: 4, 6 or 9; ER_NW_FC1: 4 or 12).  Exact mode: qkv 6 waves x 1 row
     // = 768 workgroups (3 per CU), fc1 4 waves x 2 rows = 768; fast mode: one fat workgroup per CU (9 / 12 waves x 2 rows).  The other
@@ -253,6 +256,10 @@ static void free_kv(er_ctx* c) {
     c->kc = c->vc = c->ypre = c->hbuf = c->ypre1 = c->h1buf = c->qbuf = c->abuf = c->fbuf = c->logits = c->part = nullptr;
     if (c->skpart) hipFree(c->skpart);
     c->skpart = nullptr;
+    for (void** p : {&c->xt_h, &c->xt_att, &c->xt_f}) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
     if (c->part_ml) hipFree(c->part_ml);
     c->part_ml = nullptr;
     if (c->state_block) hipFree(c->state_block);
@@ -616,7 +623,8 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     c->nch3 = attn3_num_chunks(H);
     HIPCHK(hipMalloc(&c->part, b * H * (size_t)std::max(S * (D + 2), c->nch3 * D) * 4));
     HIPCHK(hipMalloc(&c->part_ml, b * H * (size_t)c->nch3 * 2 * 4));
-    HIPCHK(hipMalloc(&c->skpart, (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
+    // split-K partials of the batched fc2: one [4][32][hidden] block per group of 32 rows (a deferred finish reads them a launch later)
+    HIPCHK(hipMalloc(&c->skpart, ((b + NBM - 1) / NBM) * (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
     c->st.tok = sb; c->st.pos = sb + b; c->st.counter = sb + 2 * b; c->st.ngen = sb + 3 * b;
@@ -643,6 +651,20 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     if (c->batched && !c->batched_valu) ERCHK(make_tiled_weights(c));
     c->stream_attn = plan.attn_kernel == ER_ATTN_STREAM;
     c->v3 = plan.decode_version == 3;
+    // fast mode, matrix-core projections: the activations travel in the tiled hi | lo operand layout (k_gemv.h xt_entry).  One image
+    // of K x 128 bytes per group of 32 rows; zeroed once so that the rows of a last, partial group never hold NaN patterns.
+    const char* xe = getenv("ER_XT");
+    c->xt = c->fast && c->batched && !c->batched_valu && !(xe && xe[0] == '0');
+    if (c->xt) {
+        const size_t groups = (size_t)(batch + NBM - 1) / NBM;
+        const size_t b_h = groups * (size_t)hid * 128, b_f = groups * (size_t)g.intermediate_dim * 128;
+        HIPCHK(hipMalloc(&c->xt_h, b_h));
+        HIPCHK(hipMalloc(&c->xt_att, b_h));
+        HIPCHK(hipMalloc(&c->xt_f, b_f));
+        HIPCHK(hipMemset(c->xt_h, 0, b_h));
+        HIPCHK(hipMemset(c->xt_att, 0, b_h));
+        HIPCHK(hipMemset(c->xt_f, 0, b_f));
+    }
     return ER_OK;
 }
 
@@ -728,12 +750,14 @@ static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) 
     }
     return hipSuccess;
 }
-template <typename WT, int EPI>
-static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st) {
+// XT: a.xin is the tiled image of the input (a group of 32 rows is K * 32 floats there as well, so the group offsets coincide)
+template <typename WT, int EPI, bool XT = false>
+static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st, bool defer_finish = false) {
     for (int b = 0; b < B; b += NBM) {
         const int nb = (B - b) < NBM ? (B - b) : NBM;
         GemvArgs g = a;
         if (g.xin) g.xin += (long long)b * K;
+        if (g.xt_out) g.xt_out = (char*)g.xt_out + (long long)b * a.N * 4;     // xt_entry() indexes inside a group
         if (g.hout) g.hout += (long long)b * K;
         if (g.tok) g.tok += b;
         if (g.pos) g.pos += b;
@@ -743,7 +767,8 @@ static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStr
         const long long kvb = (long long)b * a.kv_bstride * (a.kv_half ? 2 : 4);
         if (g.kcache) g.kcache = (char*)g.kcache + kvb;
         if (g.vcache) g.vcache = (char*)g.vcache + kvb;
-        hipError_t e = launch_gemv_mfma<WT, EPI>(g, nb, K, part, st);
+        // deferred: every group keeps its own partial block (prep_rows_kernel: g * 4 * 32 * K floats)
+        hipError_t e = launch_gemv_mfma<WT, EPI, XT>(g, nb, K, defer_finish ? part + (long long)(b / NBM) * 4 * NBM * a.N : part, st, defer_finish);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -772,6 +797,7 @@ static AttnDecArgs attn_args(er_ctx* c, int layer) {
     a.hidden = c->cfg.hidden_dim;
     a.kv_bstride = c->kv_bstride;
     a.sqrt_d = sqrtf((float)c->D);
+    a.out_xt = (c->xt && c->stream_attn && c->B > 8) ? c->xt_att : nullptr;      // out_proj then reads the tiled image (launch_kind_t case 3)
     return a;
 }
 
@@ -805,9 +831,20 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 a.xin = c->ypre; a.ln_w = c->layers[layer - 1].ln2w; a.ln_b = c->layers[layer - 1].ln2b;
             }
             if (c->batched) {
+                if constexpr (HALF) {
+                    a.xt_out = c->xt ? c->xt_h : nullptr;
+                    if (c->xt && layer > 0) {      // the previous layer's fc2 deferred its split-K finish to this LayerNorm (case 5)
+                        a.sk_part = c->skpart; a.sk_bias = c->layers[layer - 1].b2; a.sk_resid = c->h1buf; a.sk_batch = B;
+                    }
+                }
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
+                a.sk_part = nullptr;
                 if (e != hipSuccess) return e;
                 a.xin = c->hbuf;
+                a.xt_out = nullptr;
+                if constexpr (HALF) {
+                    if (c->xt) { a.W = L.wqkv_t; a.xin = (const float*)c->xt_h; return gemv_mfma_groups<WT, EPI_QKV, true>(a, B, H, c->skpart, st); }
+                }
                 if (!c->batched_valu) { a.W = L.wqkv_t; return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, c->skpart, st); }   // 144 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_QKV>(a, B, H, st);   // 4608 rows = 192 workgroups x 24: one round
             }
@@ -835,6 +872,9 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             // 48 row tiles of 32: the matrix-core kernel runs on 48 CUs only, but streams the matrix ONCE for 32 rows where the
             // VALU kernel needs a pass per 16
             if (c->batched && !c->batched_valu && B >= 5 && B <= 8) return gemv_outproj_rows8<WT>(a, B, st);
+            if constexpr (HALF) {
+                if (c->xt && c->stream_attn && B > 8) { a.W = L.wo_t; a.xin = (const float*)c->xt_att; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, H, c->skpart, st); }
+            }
             if (c->batched && !c->batched_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, c->skpart, st); }
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
             return gemv_groups<WT, 1, 1, PRO_NONE, EPI_RESID, 3>(a, B, H, st);     // 3 waves x 1 row: 512 workgroups = 2 per CU
@@ -844,9 +884,17 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             a.W = HALF ? (const void*)L.w1_h : (const void*)L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
             a.hout = c->h1buf; a.out = c->fbuf;
             if (c->batched) {
+                if constexpr (HALF) a.xt_out = c->xt ? c->xt_h : nullptr;
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
                 if (e != hipSuccess) return e;
                 a.xin = c->h1buf;
+                a.xt_out = nullptr;
+                if constexpr (HALF) {
+                    if (c->xt) {      // input and output both tiled: fc2 below reads xt_f
+                        a.W = L.w1_t; a.xin = (const float*)c->xt_h; a.xt_out = c->xt_f;
+                        return gemv_mfma_groups<WT, EPI_RELU, true>(a, B, H, c->skpart, st);
+                    }
+                }
                 if (!c->batched_valu) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, c->skpart, st); }   // 192 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_RELU>(a, B, H, st);   // 6144 rows = 256 workgroups x 24
             }
@@ -855,6 +903,11 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
         case 5: {   // ypre = fc2 f + b + h1
             const LayerW& L = c->layers[layer];
             a.W = HALF ? (const void*)L.w2_h : (const void*)L.w2; a.bias = L.b2; a.N = H; a.xin = c->fbuf; a.out = c->ypre; a.resid = c->h1buf;
+            if constexpr (HALF) {
+                // layers 0 .. nl-2 leave the four K-range partials to the next layer's LayerNorm launch (case 0); the last layer finishes
+                // into ypre, which the lm_head reads (after a prefill ypre comes from the GEMM path, so case 6 always reads ypre)
+                if (c->xt) { a.W = L.w2_t; a.xin = (const float*)c->xt_f; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, I, c->skpart, st, layer + 1 < nl); }
+            }
             if (c->batched && !c->batched_valu) { a.W = L.w2_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st); }   // 48 tiles x 4 K-ranges
             if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);
             return gemv_groups<WT, 4, 2, PRO_NONE, EPI_RESID>(a, B, I, st);

@@ -17,6 +17,7 @@
 // a second tiny kernel merges the partials of a head exactly as one softmax would.
 #pragma once
 #include "er_common.h"
+#include "k_gemv.h"
 
 // timeline hooks of scripts/probes/attn_timeline_probe.hip (expand to nothing in the library build)
 #ifndef ER_TP
@@ -41,6 +42,7 @@ struct AttnDecArgs {
     float sqrt_d;          // sqrt(D): scores are divided by it, as the reference does
     const int* len_src;    // filled by the version-3 launcher: len = len_src[b] + len_add (len_dev + 0, or pos + 1) unless fixed_len > 0
     int len_add;
+    void* out_xt;          // streaming kernel: also write the output row in the tiled hi | lo layout of k_gemv.h xt_entry (out_proj's input)
 };
 
 __device__ __forceinline__ int attn_len(const AttnDecArgs& a, int b) {
@@ -755,7 +757,15 @@ __global__ __launch_bounds__(ER_WG) void attn_stream_kernel(AttnDecArgs a) {
             ov = fmaf((src[0] + src[D]) + (src[2 * D] + src[3 * D]), w, ov);
             lv = fmaf(wl[k], w, lv);
         }
-        a.out[(long long)b * a.hidden + h * D + tid] = ov / lv;
+        const float r = ov / lv;
+        a.out[(long long)b * a.hidden + h * D + tid] = r;
+        if (a.out_xt) {        // element k = h D + tid of row b: halves (k & 3) [hi] and 4 + (k & 3) [lo] of entry (k >> 2, b)
+            const int k = h * D + tid;
+            _Float16* e = reinterpret_cast<_Float16*>(a.out_xt) + xt_entry(a.hidden, b, k >> 2) * 8 + (k & 3);
+            const _Float16 hi = (_Float16)r;
+            e[0] = hi;
+            e[4] = (_Float16)(r - (float)hi);
+        }
     }
 }
 

@@ -48,7 +48,38 @@ struct GemvArgs {
     int kv_half;           //          1: the cache holds _Float16
     int hidden, head_dim, l_cap;
     long long kv_bstride;  // H*Lcap*D
+    // fast-mode batches on the matrix cores (k_gemv_mfma.h, XT): activations exchanged in the matrix cores' own operand layout
+    void* xt_out;          // prep_rows / EPI_RELU: also (resp. instead) write the row in the tiled hi | lo layout xt_entry() describes
+    // prep_rows<PRO_LN> reading a DEFERRED split-K finish (the previous layer's fc2, k_gemv_mfma.h): its input row is
+    // ((p0 + p1 + p2 + p3) + sk_bias) + sk_resid - splitk_finish_kernel's sum and gemv_epilogue<EPI_RESID>'s adds, in their order
+    const float* sk_part;  // [groups][4][rows of the group][K] partials (null: read xin)
+    const float* sk_bias;  // [K]
+    const float* sk_resid; // [B][K]
+    int sk_batch;          // B: a group holds min(32, B - 32 g) rows
 };
+
+// ---- tiled activations for the batched matrix-core projections (fast mode).  A group of 32 batch rows x K columns is stored as
+// [K/4][32][8 halves]: entry (k4, b) = 16 bytes = {hi(x[b][4 k4 .. 4 k4+3]), lo(...)} with x = hi + lo (hi = (fp16)x, lo = (fp16)(x - hi)):
+// exactly the B operands of the two v_mfma_f32_16x16x16_f16 a lane issues per weight quad, so the consumer's wave-load is 4 runs of
+// 256 contiguous bytes (16 batch rows x 16 B) instead of 16 rows x 64 B out of 128-byte lines 6 KiB apart, and nobody converts on
+// the consumer side (round 3: every one of the 144..192 workgroups re-split the whole [32][1536] input; profiles/r04_batch_kinds_*).
+// Group g of a batch (rows 32 g ..) starts K * 32 floats behind group g - 1: the same offset as 32 row-major rows.
+typedef _Float16 xt_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 xt_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ long long xt_entry(int K, int b, int k4) {            // index of the 16-byte entry (in entries)
+    return (long long)(b >> 5) * (K / 4) * 32 + (long long)k4 * 32 + (b & 31);
+}
+__device__ __forceinline__ xt_h8 xt_pack(float x0, float x1, float x2, float x3) {
+    xt_h8 r;
+    const float xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hi = (_Float16)xs[e];
+        r[e] = hi;
+        r[4 + e] = (_Float16)(xs[e] - (float)hi);
+    }
+    return r;
+}
 
 // Weight storage types: fp32 (exact mode) or fp16 (fast mode, fp32 accumulate).  One 16-byte load
 // carries EPL weights; the matching EPL inputs are EPL/4 consecutive float4.
@@ -510,10 +541,34 @@ __global__ __launch_bounds__(ER_WG) void prep_rows_kernel(GemvArgs a) {
 #pragma unroll
         for (int i = 0; i < PT; ++i) v[i] = e[tid + i * ER_WG] + p[tid + i * ER_WG];
     } else {
-        const float* x = a.xin + (long long)b * K;
         float lw[PT], lb[PT];                  // loaded with the row, not behind the two reductions (a dependent round trip per launch)
+        if (a.sk_part) {
+            // the previous layer's fc2 left its four K-range partials unfinished (23 of 24 splitk_finish launches per token removed):
+            // every load of the row goes out at once, the adds keep splitk_finish_kernel's / gemv_epilogue's order
+            const int g = b >> 5, nbg = min(32, a.sk_batch - 32 * g);
+            const float* p0 = a.sk_part + ((long long)g * 4 * 32 + (b & 31)) * K;       // slice s of the group: + s * nbg * K
+            float p[4][PT], bs[PT], rs[PT];
 #pragma unroll
-        for (int i = 0; i < PT; ++i) { v[i] = x[tid + i * ER_WG]; lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG]; }
+            for (int i = 0; i < PT; ++i) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[k][i] = p0[(long long)k * nbg * K + tid + i * ER_WG];
+                bs[i] = a.sk_bias[tid + i * ER_WG];
+                rs[i] = a.sk_resid[(long long)b * K + tid + i * ER_WG];
+                lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG];
+            }
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s += p[k][i];
+                s += bs[i];
+                v[i] = s + rs[i];
+            }
+        } else {
+            const float* x = a.xin + (long long)b * K;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) { v[i] = x[tid + i * ER_WG]; lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG]; }
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < PT; ++i) s += v[i];
@@ -528,6 +583,17 @@ __global__ __launch_bounds__(ER_WG) void prep_rows_kernel(GemvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < PT; ++i) a.hout[(long long)b * K + tid + i * ER_WG] = v[i];
+    if (a.xt_out) {        // the same row in the matrix cores' operand layout: through LDS, so that a thread holds four consecutive k
+        __shared__ __attribute__((aligned(16))) float row[K];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) row[tid + i * ER_WG] = v[i];
+        __syncthreads();
+        xt_h8* xt = reinterpret_cast<xt_h8*>(a.xt_out);
+        for (int k4 = tid; k4 < K / 4; k4 += ER_WG) {
+            const f32x4 t = reinterpret_cast<const f32x4*>(row)[k4];
+            xt[xt_entry(K, b, k4)] = xt_pack(t.x, t.y, t.z, t.w);
+        }
+    }
 }
 
 }  // namespace er

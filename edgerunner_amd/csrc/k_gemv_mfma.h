@@ -27,8 +27,11 @@ constexpr int GM_WAVES = 16, GM_THREADS = GM_WAVES * 64, GM_R2 = 2, GM_ROWS = 16
 
 // A workgroup = 16 waves = a 32-row tile (two 16-row A tiles per wave, sharing the X registers: X comes from L2 once
 // per 32 weight rows) x 16 K-slices of 96 = K-range 1536.  NBH = 16-row batch halves (1 or 2); SPLIT: raw partials.
-template <typename WT, int NBH, int EPI, bool SPLIT>
+// XT (fast mode only): a.xin is the tiled hi | lo image of the input (k_gemv.h xt_entry) instead of row-major fp32 - same values, same
+// MFMA sequence, bit-identical results; EPI_RELU then writes its output in that layout too (a.xt_out: the next projection's input).
+template <typename WT, int NBH, int EPI, bool SPLIT, bool XT = false>
 __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int nb_valid, int K, float* part) {
+    static_assert(!XT || sizeof(WT) == 2, "the tiled activation layout feeds the fp16 matrix cores");
     constexpr int EPL = WTraits<WT>::EPL;            // weights per 16-byte load: 4 (fp32) or 8 (fp16)
     constexpr int NLD = GM_KW / (4 * EPL);           // loads per lane and row tile: a wave-load covers 16 rows x 4*EPL k
     constexpr int XV = EPL / 4;
@@ -43,11 +46,20 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     f32x4 x[NBH][NLD][XV];
 #pragma unroll
     for (int h = 0; h < NBH; ++h) {
-        const float* xp = a.xin + (long long)min(h * 16 + li, nb_valid - 1) * K + kbase;
+        if constexpr (XT) {
+            // entry (k4, b): lanes li = 16 consecutive batch rows = 256 contiguous bytes, kq / u / c step whole k-quads (512 B each)
+            const f32x4* xp = reinterpret_cast<const f32x4*>(a.xin) + (long long)(kbase / 4) * 32 + h * 16 + li;
 #pragma unroll
-        for (int c = 0; c < NLD; ++c)
+            for (int c = 0; c < NLD; ++c)
 #pragma unroll
-            for (int u = 0; u < XV; ++u) x[h][c][u] = *reinterpret_cast<const f32x4*>(xp + c * 4 * EPL + 4 * u);
+                for (int u = 0; u < XV; ++u) x[h][c][u] = xp[(c * EPL + u) * 32];
+        } else {
+            const float* xp = a.xin + (long long)min(h * 16 + li, nb_valid - 1) * K + kbase;
+#pragma unroll
+            for (int c = 0; c < NLD; ++c)
+#pragma unroll
+                for (int u = 0; u < XV; ++u) x[h][c][u] = *reinterpret_cast<const f32x4*>(xp + c * 4 * EPL + 4 * u);
+        }
     }
     f32x4 w[GM_R2][NLD];
     const f32x4* wp[GM_R2];
@@ -89,14 +101,21 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
 #pragma unroll
             for (int h = 0; h < NBH; ++h)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (XT) {        // the producer split the value: halves 0..3 = hi, 4..7 = lo of this k-quad
+                        const f16x8 t = __builtin_bit_cast(f16x8, x[h][c][j]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float xv = x[h][c][j][e];
-                        const _Float16 hi = (_Float16)xv;
-                        xh[h][j][e] = hi;
-                        xl[h][j][e] = (_Float16)(xv - (float)hi);
+                        for (int e = 0; e < 4; ++e) { xh[h][j][e] = t[e]; xl[h][j][e] = t[4 + e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xv = x[h][c][j][e];
+                            const _Float16 hi = (_Float16)xv;
+                            xh[h][j][e] = hi;
+                            xl[h][j][e] = (_Float16)(xv - (float)hi);
+                        }
                     }
+                }
 #pragma unroll
             for (int t = 0; t < GM_R2; ++t) {
                 const f16x8 hv = __builtin_bit_cast(f16x8, w[t][c]);
@@ -142,7 +161,14 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
         float s = 0.f;
 #pragma unroll
         for (int wv = 0; wv < GM_WAVES; ++wv) s += red[wv][slot][ol][orr];
-        if (active) {
+        if (XT && !SPLIT && EPI == EPI_RELU) {
+            // fc1 -> fc2: the four threads orr = 0..3 hold four consecutive columns of one batch row = one tiled entry of the next
+            // projection's input; the quad's values meet in thread orr = 0 (DPP quad_perm), which stores the 16 bytes
+            float v = fmaxf(s + pre.bias, 0.0f);
+            if (!active) v = 0.f;
+            const float v1 = dpp_mov<0x39>(v), v2 = dpp_mov<0x4E>(v), v3 = dpp_mov<0x93>(v);   // quad_perm [1,2,3,0] / [2,3,0,1] / [3,0,1,2]: lane 0 of a quad reads lanes 1 / 2 / 3
+            if (active && orr == 0) reinterpret_cast<xt_h8*>(a.xt_out)[xt_entry(a.N, ob, on >> 2)] = xt_pack(v, v1, v2, v3);
+        } else if (active) {
             if (SPLIT) part[((long long)blockIdx.y * nb_valid + ob) * a.N + on] = s;
             else gemv_epilogue<EPI>(a, on, ob, s, pre);
         }
@@ -192,21 +218,22 @@ __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const 
 }
 
 // one pass over <= 32 rows; K = ksplit * 1536; a.W must point at the TILED copy of the matrix.  `part` must hold ksplit * nb_valid * N floats when ksplit > 1.
-template <typename WT, int EPI>
-inline hipError_t launch_gemv_mfma(const GemvArgs& a, int nb_valid, int K, float* part, hipStream_t st) {
+// defer_finish: a split-K launch leaves its partials in `part` (the consumer - prep_rows_kernel with sk_part - finishes them)
+template <typename WT, int EPI, bool XT = false>
+inline hipError_t launch_gemv_mfma(const GemvArgs& a, int nb_valid, int K, float* part, hipStream_t st, bool defer_finish = false) {
     const int ksplit = K / (GM_WAVES * GM_KW);
     if (K != ksplit * GM_WAVES * GM_KW) return hipErrorInvalidValue;
     const dim3 grid((a.N + GM_ROWS - 1) / GM_ROWS, ksplit);
     const bool two = nb_valid > 16;
     if (ksplit == 1) {
-        if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, false>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
-        else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, false>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+        if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, false, XT>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+        else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, false, XT>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
         return hipGetLastError();
     }
-    if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, true>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
-    else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, true>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+    if (two) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, true, XT>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
+    else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, true, XT>), grid, dim3(GM_THREADS), 0, st, a, nb_valid, K, part);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || defer_finish) return e;
     const long long total = (long long)nb_valid * a.N;
     hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3((unsigned)((total + ER_WG - 1) / ER_WG)), dim3(ER_WG), 0, st, a, part, ksplit,
                        nb_valid);

@@ -100,6 +100,18 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, device=None) -> List[float]:
+    """The same scalar from every rank, in rank order (one all-gather of 8 bytes per rank; diagnostics of bench.py --gpus N)."""
+    if not _collectives_on():
+        return [float(value)]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 # ------------------------------------------------------------------------------------------------
 # Job planning of the drop-in scripts (reference infer.py:99-101,136-137: serial loops path x repeat x num_face)
 def plan_jobs(paths: Sequence[str], test_repeat: int, test_num_face: Sequence[int], rank: int, world: int):

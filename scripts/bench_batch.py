@@ -44,7 +44,9 @@ def main():
                 assert t in st.allowed(last) and t != 2, (r, t)
                 last = t
         distinct = len({tuple(t[:256]) for t in toks})
-        print(json.dumps({"precision": precision, "mode": mode, "B": B, "T": T, "distinct_rows": distinct, "decode_ms": round(ms, 1), "ms_per_step": round(ms / T, 3),
+        import zlib
+        crc = zlib.crc32(b"".join(t.tobytes() for t in toks))          # A/B runs (ER_XT=0 / 1, library builds) must agree on every id
+        print(json.dumps({"precision": precision, "mode": mode, "B": B, "T": T, "distinct_rows": distinct, "ids_crc": crc, "decode_ms": round(ms, 1), "ms_per_step": round(ms / T, 3),
                           "aggregate_tok_s": round(B * T / ms * 1e3, 1), "end_to_end_tok_s": round(B * T / wall, 1),
                           "algorithmic_GBps": round(bytes_step / (ms / T * 1e-3) / 1e9, 1),
                           }), flush=True)

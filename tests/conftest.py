@@ -67,6 +67,14 @@ def gold_batch():
 
 
 @pytest.fixture(scope="session")
+def gold_long24():
+    p = os.path.join(GOLDEN, "arae_long24.npz")
+    if not os.path.exists(p):
+        pytest.skip("full-depth long-context golden not generated (oracle/make_golden.py long24)")
+    return dict(np.load(p))
+
+
+@pytest.fixture(scope="session")
 def gold_long():
     p = os.path.join(GOLDEN, "arae_long.npz")
     if not os.path.exists(p):

@@ -24,6 +24,10 @@ def run_bench(*args):
 def test_bench_spawns_its_ranks_dry_run(gpus, batch):
     out, err = run_bench("--gpus", gpus, "--dry-run", "--steps", 2, "--warmup", 1, "--tokens", 64, "--batch-per-gpu", batch)
     assert out["dry_run"] is True and out["n_gpus"] == gpus and out["world_size_seen"] == gpus
+    # the per-rank diagnostics a first real multi-GPU run needs: every rank reported its wall and gather time
+    pr = out["per_rank"]
+    assert pr["ranks_reporting"] == gpus and 0 <= pr["wall_s"]["min"] <= pr["wall_s"]["max"]
+    assert 0 <= pr["gather_ms_per_step"]["min"] <= pr["gather_ms_per_step"]["max"]
     assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak" and out["higher_is_better"] is True
     assert out["config"]["batch_per_gpu"] == batch
     assert out["value"] > 0

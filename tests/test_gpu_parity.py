@@ -358,6 +358,111 @@ def test_long_context_batch_ids_and_logits(gold_long, B):
     lmm.mesh_decoder.reserve(1, 4096)
 
 
+# ------------------------------------------------------------------ the same at FULL DEPTH: 24 layers, contexts 14050+ / 18050+
+def _long24_batch(B, R, seed0, golden_row=0):
+    """B rows of R resumed tokens each; row `golden_row` holds the golden's cloud 0 / resume seed, the others their own."""
+    from edgerunner_amd import weights as W
+    clouds = [0 if r == golden_row else 40 + r for r in range(B)]
+    resume = np.stack([W.synthetic_resume_ids(seed0 if r == golden_row else seed0 + 100 + r, R) for r in range(B)])
+    return torch.cat([cloud(c) for c in clouds]), torch.as_tensor(resume)
+
+
+def _teacher_forced_batch(lmm, batch, num_faces, resume, gold_ids, gold_logits, row, T):
+    dec, opt = lmm.mesh_decoder, lmm.opt
+    B = batch.shape[0]
+    cond = lmm.encode_cond(batch, [num_faces] * B)["cond_embeds"]
+    inp = torch.cat((torch.full((B, 1), opt.bos_token_id, dtype=torch.long), resume), dim=1)
+    dec.prefill(torch.cat((cond, dec.embd(inp)), dim=1), T + 2)
+    err = 0.0
+    for t in range(T):
+        lg = dec.logits().cpu().numpy()
+        err = max(err, float(np.abs(lg[row] - gold_logits[t]).max()))
+        if t < T - 1:
+            dec.feed([int(gold_ids[t])] * B)           # every row is fed the golden row's id (legal for all: same grammar state)
+    return err
+
+
+def test_full_depth_long_context_single_row(gold_long24):
+    """24 layers, 12000 resumed tokens: greedy ids bit-exact and teacher-forced logits <= 1e-3 against the reference's own modules at
+    contexts 14050..14066 through the single-row fallback (reserved cache > 8192 keys: fixed-chunk attention + merge kernel)."""
+    import zlib
+    from edgerunner_amd import native
+    from edgerunner_amd import weights as W
+    lmm = make_lmm(num_layers=24)
+    T, R = int(gold_long24["T"][0]), int(gold_long24["R"][0])
+    res = W.synthetic_resume_ids(500, R)
+    assert zlib.crc32(res.astype(np.int64).tobytes()) == int(gold_long24["resume_crc32"][0])
+    resume = torch.as_tensor(res)[None]
+    _, toks = lmm.generate(cloud(0), 4000, resume_ids=resume, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+    plan = lmm.mesh_decoder.plan()
+    assert plan["decode_version"] == 2 and plan["attn_kernel"] == native.ER_ATTN_SPLIT2, plan
+    assert_ids(toks[0][R:], gold_long24["ids"], "24 layers, continuation after 12000 resumed tokens (fallback kernels)")
+    got = teacher_forced_logits(lmm, cloud(0), 4000, gold_long24["ids"], set(range(T)), resume_ids=resume)
+    err = max(float(np.abs(got[t] - gold_long24["logits"][t]).max()) for t in range(T))
+    print(f"24 layers, single row, context {2050 + R}..: teacher-forced max|dlogit| {err:.3e}")
+    assert err < LOGIT_TOL
+    lmm.mesh_decoder.reserve(1, 4096)
+
+
+@pytest.mark.parametrize("B", [18, 6])
+def test_full_depth_long_context_batch(gold_long24, B):
+    """The same golden through the batched kernels at 24 layers: B = 18 (streaming attention), B = 6 (split kernel + merge);
+    the golden row sits at index 2, its neighbours hold other clouds and other resumed prefixes."""
+    from edgerunner_amd import native
+    lmm = make_lmm(num_layers=24)
+    T, R = int(gold_long24["T"][0]), int(gold_long24["R"][0])
+    batch, resume = _long24_batch(B, R, 500, golden_row=2)
+    _, toks = lmm.generate(batch, 4000, resume_ids=resume, tokenizer=object(), max_new_tokens=T, min_new_tokens=T)
+    plan = lmm.mesh_decoder.plan()
+    assert plan["attn_kernel"] == (native.ER_ATTN_STREAM if B == 18 else native.ER_ATTN_SPLIT1), plan
+    assert_ids(toks[2][R:], gold_long24["ids"], f"24 layers, B = {B}, golden row after 12000 resumed tokens")
+    err = _teacher_forced_batch(lmm, batch, 4000, resume, gold_long24["ids"], gold_long24["logits"], 2, T)
+    print(f"24 layers, B = {B}, context {2050 + R}..: teacher-forced max|dlogit| {err:.3e}")
+    assert err < LOGIT_TOL
+    lmm.mesh_decoder.reserve(1, 4096)
+
+
+def test_config2_shape_at_its_real_context_fp16_streaming(gold_long24):
+    """BASELINE configs[2]'s shape at the context it actually reaches: 24 layers, fp16 storage (fast mode), face bucket 3, 16000
+    resumed tokens -> contexts 18050..18058, a 16-row batch so that the STREAMING attention kernel walks 18 k keys per (row, head).
+    Teacher-forced along the fp16-storage emulation's greedy path (oracle restatement, pinned to the reference modules by the fp32
+    goldens): every arg-max equals the golden id and the logits agree to the fast-mode tolerance."""
+    import zlib
+    from edgerunner_amd import native
+    from edgerunner_amd import weights as W
+    lmm = make_lmm(num_layers=24, precision="fp16")
+    T, R = int(gold_long24["T2"][0]), int(gold_long24["R2"][0])
+    assert zlib.crc32(W.synthetic_resume_ids(900, R).astype(np.int64).tobytes()) == int(gold_long24["resume2_crc32"][0])
+    B = 16
+    batch, resume = _long24_batch(B, R, 900, golden_row=5)
+    dec, opt = lmm.mesh_decoder, lmm.opt
+    cond = lmm.encode_cond(batch, [4000] * B)["cond_embeds"]
+    inp = torch.cat((torch.full((B, 1), opt.bos_token_id, dtype=torch.long), resume), dim=1)
+    dec.prefill(torch.cat((cond, dec.embd(inp)), dim=1), T + 2)
+    plan = dec.plan()
+    assert plan["attn_kernel"] == native.ER_ATTN_STREAM, plan
+    import arae_oracle as O
+    from edgerunner_amd.options import config_defaults
+    ids, want = gold_long24["ids_fp16"], gold_long24["logits_fp16"]
+    fn = O.make_allowed_fn(config_defaults["ArAE"], 518)
+    hist = torch.empty(0, dtype=torch.long)
+    err = 0.0
+    for t in range(T):
+        lg = dec.logits().cpu()[5]
+        err = max(err, float(np.abs(lg.numpy() - want[t]).max()))
+        sc = lg.clone()
+        sc[opt.eos_token_id] = -float("inf")                       # min_new_tokens == T in the golden run
+        mask = torch.full_like(sc, -float("inf"))
+        mask[fn(0, hist)] = 0
+        assert int(torch.argmax(sc + mask)) == int(ids[t]), (t, "grammar-masked arg-max of the device logits != golden id")
+        hist = torch.cat([hist, torch.tensor([int(ids[t])])])
+        if t < T - 1:
+            dec.feed([int(ids[t])] * B)
+    print(f"24 layers, fp16 storage, B = 16, context {2050 + R}..: teacher-forced max|dlogit| vs the fp16 emulation {err:.3e}")
+    assert err < LOGIT_TOL
+    lmm.mesh_decoder.reserve(1, 4096)
+
+
 # ------------------------------------------------------------------ host callable path, sample mode
 def test_stepwise_callable_path_matches_device(gold_small):
     from edgerunner_amd.grammar import as_callable

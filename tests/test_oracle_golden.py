@@ -133,6 +133,29 @@ def test_long_context_golden_is_well_formed(gold_long, manifest):
             hist = torch.cat([hist, torch.tensor([int(gold_long["ids"][i, t])])])
 
 
+def test_full_depth_long_context_golden_is_well_formed(gold_long24, manifest):
+    """arae_long24.npz (24 layers: fp32 reference modules at contexts 14050.., fp16 emulation at 18050..): resumed prefixes match
+    their CRCs, contexts are what the GPU tests assume, every golden id is the grammar-masked arg max of its recorded logits."""
+    import zlib
+    from edgerunner_amd import weights as W
+    m = manifest["arae_long24"]
+    assert m["num_layers"] == 24
+    fn = O.make_allowed_fn(config_defaults["ArAE"], 518)
+    for ids_k, lg_k, crc_k, R_k, T_k, seed, ctx in (("ids", "logits", "resume_crc32", "R", "T", 500, m["fp32"]["context"]),
+                                                     ("ids_fp16", "logits_fp16", "resume2_crc32", "R2", "T2", 900, m["fp16"]["context"])):
+        R, T = int(gold_long24[R_k][0]), int(gold_long24[T_k][0])
+        assert ctx == [2050 + R, 2050 + R + T] and 2050 + R > 8192
+        assert zlib.crc32(W.synthetic_resume_ids(seed, R).astype(np.int64).tobytes()) == int(gold_long24[crc_k][0])
+        hist = torch.empty(0, dtype=torch.long)
+        for t in range(T):
+            s = torch.from_numpy(gold_long24[lg_k][t]).clone()
+            s[2] = -float("inf")
+            mask = torch.full_like(s, -float("inf"))
+            mask[fn(0, hist)] = 0
+            assert int(torch.argmax(s + mask)) == int(gold_long24[ids_k][t]), (ids_k, t)
+            hist = torch.cat([hist, torch.tensor([int(gold_long24[ids_k][t])])])
+
+
 # ------------------------------------------------------------------ DiT / CLIP front-end (scope row f3)
 @pytest.fixture(scope="module")
 def gold_dit():
