@@ -44,8 +44,8 @@ KV_ELEMS_PER_POS = 73_728      # 2 * 24 * 1536
 PREFIX = 2050                  # 2049 condition tokens + BOS
 LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "out_proj_gemv": 24, "fc1_gemv": 24,
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
-# committed rocprofv3 PMC summaries (scripts/gpu_round3.sh pmc / pmc3): single-row decode kernels, batched (B = 32) decode kernels
-PMC_SUMMARY = {False: os.path.join("profiles", "r03_pmc_hbm_summary.json"), True: os.path.join("profiles", "r03_pmc_hbm_config3_summary.json")}
+# committed rocprofv3 PMC summaries (scripts/gpu_round4.sh pmc / pmc3): single-row decode kernels, batched (B = 32) decode kernels
+PMC_SUMMARY = {False: os.path.join("profiles", "r04_pmc_hbm_summary.json"), True: os.path.join("profiles", "r04_pmc_hbm_config3_summary.json")}
 # the single-GPU configurations of BASELINE.json (configs[0] is the CPU path = cpu_baseline; configs[4] = dit_front_end_fp16)
 CONFIGS = {
     1: {"name": "BASELINE configs[1]", "batch": 1, "num_face": 1000, "mode": "greedy", "precision": "fp32"},
@@ -107,8 +107,8 @@ def spawn_ranks(args) -> int:
 
 
 def pmc_traffic(kind, kernel_names, at_len, batched=False):
-    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes (profiles/r03_pmc_hbm_*summary.json:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes; separate --pmc runs, scripts/gpu_round3.sh pmc / pmc3).  Counters
+    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc_hbm_*summary.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes; separate --pmc runs, scripts/gpu_round4.sh pmc / pmc3).  Counters
     cannot be read inside the timed process.  The attention passes run at a recorded context length (the PMC run starts its
     decode at --resume-len); its bytes are scaled linearly to `at_len` keys, the length `bytes_per_launch` is quoted at."""
     path = os.path.join(ROOT, PMC_SUMMARY[bool(batched)])
@@ -443,7 +443,7 @@ def main(argv=None):
         "context_len_at_measurement": L_ref,
         "note": f"run-average: mean launch duration over {NS} contexts spread over the timed run (contexts {L0 + 1}..{L0 + T}) and "
                 "the algorithmic bytes of one launch at the mean context length; reproduce with scripts/roofline_from_rocprof.py "
-                "on profiles/r03_*_kernel_stats.csv",
+                "on profiles/r04_*_kernel_stats.csv",
         "context_sweep": ends,
         "per_layer_kernel_sum_us": round(layer_us, 2),
         "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1) if v["avg_us"] > 0 else 0.0,

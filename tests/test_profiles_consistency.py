@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 
 
-@pytest.mark.parametrize("csv,line", [("r03_bench_kernel_stats.csv", "r03_bench.json"),
-                                      ("r03_config3_kernel_stats.csv", "r03_bench_config3.json")])
+@pytest.mark.parametrize("csv,line", [("r04_bench_kernel_stats.csv", "r04_bench.json"),
+                                      ("r04_config3_kernel_stats.csv", "r04_bench_config3.json")])
 def test_roofline_reproduces_from_rocprof_summary(csv, line):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "roofline_from_rocprof.py"), os.path.join(PROF, csv),
                         os.path.join(PROF, line), "--tol", "0.05"], capture_output=True, text=True)
@@ -22,7 +22,7 @@ def test_roofline_reproduces_from_rocprof_summary(csv, line):
 
 
 def test_bench_line_is_internally_consistent():
-    d = json.load(open(os.path.join(PROF, "r03_bench.json")))
+    d = json.load(open(os.path.join(PROF, "r04_bench.json")))
     r = d["roofline"]
     assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
     assert abs(r["bytes_per_launch"] / (r["avg_us_per_launch"] * 1e-6) / 1e9 - r["achieved"]) < 0.01 * r["achieved"]
