@@ -624,7 +624,7 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     HIPCHK(hipMalloc(&c->part, b * H * (size_t)std::max(S * (D + 2), c->nch3 * D) * 4));
     HIPCHK(hipMalloc(&c->part_ml, b * H * (size_t)c->nch3 * 2 * 4));
     // split-K partials of the batched fc2: one [4][32][hidden] block per group of 32 rows (a deferred finish reads them a launch later)
-    HIPCHK(hipMalloc(&c->skpart, ((b + NBM - 1) / NBM) * (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
+    HIPCHK(hipMalloc(&c->skpart, ((b + NBM - 1) / NBM) * (size_t)16 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
     c->st.tok = sb; c->st.pos = sb + b; c->st.counter = sb + 2 * b; c->st.ngen = sb + 3 * b;
@@ -752,7 +752,7 @@ static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) 
 }
 // XT: a.xin is the tiled image of the input (a group of 32 rows is K * 32 floats there as well, so the group offsets coincide)
 template <typename WT, int EPI, bool XT = false>
-static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st, bool defer_finish = false) {
+static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st, bool defer_finish = false, bool narrow = false) {
     for (int b = 0; b < B; b += NBM) {
         const int nb = (B - b) < NBM ? (B - b) : NBM;
         GemvArgs g = a;
@@ -768,7 +768,8 @@ static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStr
         if (g.kcache) g.kcache = (char*)g.kcache + kvb;
         if (g.vcache) g.vcache = (char*)g.vcache + kvb;
         // deferred: every group keeps its own partial block (prep_rows_kernel: g * 4 * 32 * K floats)
-        hipError_t e = launch_gemv_mfma<WT, EPI, XT>(g, nb, K, defer_finish ? part + (long long)(b / NBM) * 4 * NBM * a.N : part, st, defer_finish);
+        const int slices = narrow ? K / (4 * GM_KW) : K / (GM_WAVES * GM_KW);
+        hipError_t e = launch_gemv_mfma<WT, EPI, XT>(g, nb, K, defer_finish ? part + (long long)(b / NBM) * slices * NBM * a.N : part, st, defer_finish, narrow);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -834,7 +835,7 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 if constexpr (HALF) {
                     a.xt_out = c->xt ? c->xt_h : nullptr;
                     if (c->xt && layer > 0) {      // the previous layer's fc2 deferred its split-K finish to this LayerNorm (case 5)
-                        a.sk_part = c->skpart; a.sk_bias = c->layers[layer - 1].b2; a.sk_resid = c->h1buf; a.sk_batch = B;
+                        a.sk_part = c->skpart; a.sk_bias = c->layers[layer - 1].b2; a.sk_resid = c->h1buf; a.sk_batch = B; a.sk_slices = 16;
                     }
                 }
                 hipError_t e = layer == 0 ? prep_rows<PRO_EMBED>(a, B, st) : prep_rows<PRO_LN>(a, B, st);
@@ -873,7 +874,9 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             // VALU kernel needs a pass per 16
             if (c->batched && !c->batched_valu && B >= 5 && B <= 8) return gemv_outproj_rows8<WT>(a, B, st);
             if constexpr (HALF) {
-                if (c->xt && c->stream_attn && B > 8) { a.W = L.wo_t; a.xin = (const float*)c->xt_att; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, H, c->skpart, st); }
+                // 4-wave workgroups (48 row tiles x 4 K-ranges of 384 instead of 48 x one of 1536); + bias + residual happen in fc1's
+                // LayerNorm-rows launch (case 4), which reads the four partials
+                if (c->xt && c->stream_attn && B > 8) { a.W = L.wo_t; a.xin = (const float*)c->xt_att; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, H, c->skpart, st, true, true); }
             }
             if (c->batched && !c->batched_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, c->skpart, st); }
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
@@ -884,8 +887,14 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             a.W = HALF ? (const void*)L.w1_h : (const void*)L.w1; a.bias = L.b1; a.N = I; a.xin = c->ypre1; a.ln_w = L.ln1w; a.ln_b = L.ln1b;
             a.hout = c->h1buf; a.out = c->fbuf;
             if (c->batched) {
-                if constexpr (HALF) a.xt_out = c->xt ? c->xt_h : nullptr;
+                if constexpr (HALF) {
+                    a.xt_out = c->xt ? c->xt_h : nullptr;
+                    if (c->xt && c->stream_attn && B > 8) {      // out_proj (case 3) left four K-range partials: ypre1 = ((sum) + bo) + h
+                        a.sk_part = c->skpart; a.sk_bias = L.bo; a.sk_resid = c->hbuf; a.sk_batch = B; a.sk_slices = 4;
+                    }
+                }
                 hipError_t e = prep_rows<PRO_LN>(a, B, st);
+                a.sk_part = nullptr;
                 if (e != hipSuccess) return e;
                 a.xin = c->h1buf;
                 a.xt_out = nullptr;
@@ -906,7 +915,8 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             if constexpr (HALF) {
                 // layers 0 .. nl-2 leave the four K-range partials to the next layer's LayerNorm launch (case 0); the last layer finishes
                 // into ypre, which the lm_head reads (after a prefill ypre comes from the GEMM path, so case 6 always reads ypre)
-                if (c->xt) { a.W = L.w2_t; a.xin = (const float*)c->xt_f; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, I, c->skpart, st, layer + 1 < nl); }
+                // 4-wave workgroups: 48 row tiles x 16 K-ranges of 384 (768 workgroups = 3 per CU instead of 192 on 192 CUs)
+                if (c->xt) { a.W = L.w2_t; a.xin = (const float*)c->xt_f; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, I, c->skpart, st, layer + 1 < nl, true); }
             }
             if (c->batched && !c->batched_valu) { a.W = L.w2_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st); }   // 48 tiles x 4 K-ranges
             if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);

@@ -56,6 +56,7 @@ struct GemvArgs {
     const float* sk_bias;  // [K]
     const float* sk_resid; // [B][K]
     int sk_batch;          // B: a group holds min(32, B - 32 g) rows
+    int sk_slices;         // K-range partials per row: 4 (16-wave workgroups) or 16 (4-wave workgroups of fc2) - 0 counts as 4
 };
 
 // ---- tiled activations for the batched matrix-core projections (fast mode).  A group of 32 batch rows x K columns is stored as
@@ -527,6 +528,28 @@ inline hipError_t launch_gemv_batched(const GemvArgs& a, int nb_valid, hipStream
     return hipGetLastError();
 }
 
+// ((p_0 + p_1 + ... + p_{S-1}) + bias) + resid for the PT elements of a thread: every load first, then the adds in slice order
+template <int S, int PT>
+__device__ __forceinline__ void sk_finish_row(const float* p0, long long slice_stride, const float* bias, const float* resid, int tid,
+                                              float (&v)[PT]) {
+    float p[S][PT], bs[PT], rs[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) p[k][i] = p0[(long long)k * slice_stride + tid + i * ER_WG];
+        bs[i] = bias[tid + i * ER_WG];
+        rs[i] = resid[tid + i * ER_WG];
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) s += p[k][i];
+        s += bs[i];
+        v[i] = s + rs[i];
+    }
+}
+
 // One workgroup per batch row: the LayerNorm / embedding prologue of gemv_kernel as its own kernel
 // (identical thread->element mapping and reduction order), writing the GEMV input / residual row.
 template <int PRO>
@@ -546,24 +569,12 @@ __global__ __launch_bounds__(ER_WG) void prep_rows_kernel(GemvArgs a) {
             // the previous layer's fc2 left its four K-range partials unfinished (23 of 24 splitk_finish launches per token removed):
             // every load of the row goes out at once, the adds keep splitk_finish_kernel's / gemv_epilogue's order
             const int g = b >> 5, nbg = min(32, a.sk_batch - 32 * g);
-            const float* p0 = a.sk_part + ((long long)g * 4 * 32 + (b & 31)) * K;       // slice s of the group: + s * nbg * K
-            float p[4][PT], bs[PT], rs[PT];
+            const int S = a.sk_slices == 16 ? 16 : 4;
+            const float* p0 = a.sk_part + ((long long)g * S * 32 + (b & 31)) * K;       // slice s of the group: + s * nbg * K
 #pragma unroll
-            for (int i = 0; i < PT; ++i) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) p[k][i] = p0[(long long)k * nbg * K + tid + i * ER_WG];
-                bs[i] = a.sk_bias[tid + i * ER_WG];
-                rs[i] = a.sk_resid[(long long)b * K + tid + i * ER_WG];
-                lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG];
-            }
-#pragma unroll
-            for (int i = 0; i < PT; ++i) {
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) s += p[k][i];
-                s += bs[i];
-                v[i] = s + rs[i];
-            }
+            for (int i = 0; i < PT; ++i) { lw[i] = a.ln_w[tid + i * ER_WG]; lb[i] = a.ln_b[tid + i * ER_WG]; }
+            if (S == 16) sk_finish_row<16, PT>(p0, (long long)nbg * K, a.sk_bias, a.sk_resid + (long long)b * K, tid, v);
+            else sk_finish_row<4, PT>(p0, (long long)nbg * K, a.sk_bias, a.sk_resid + (long long)b * K, tid, v);
         } else {
             const float* x = a.xin + (long long)b * K;
 #pragma unroll

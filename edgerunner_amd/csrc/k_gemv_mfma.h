@@ -29,9 +29,14 @@ constexpr int GM_WAVES = 16, GM_THREADS = GM_WAVES * 64, GM_R2 = 2, GM_ROWS = 16
 // per 32 weight rows) x 16 K-slices of 96 = K-range 1536.  NBH = 16-row batch halves (1 or 2); SPLIT: raw partials.
 // XT (fast mode only): a.xin is the tiled hi | lo image of the input (k_gemv.h xt_entry) instead of row-major fp32 - same values, same
 // MFMA sequence, bit-identical results; EPI_RELU then writes its output in that layout too (a.xt_out: the next projection's input).
-template <typename WT, int NBH, int EPI, bool SPLIT, bool XT = false>
-__global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int nb_valid, int K, float* part) {
+// NWV = waves per workgroup = 96-wide K-slices it reduces through LDS: 16 (K-range 1536, the round-1..3 shape) or 4 (K-range 384:
+// four times the workgroups, each with a quarter of the input image to fetch - for the projections whose split-K partials a later
+// LayerNorm launch finishes anyway: out_proj and fc2 in the tiled fast-mode path).
+template <typename WT, int NBH, int EPI, bool SPLIT, bool XT = false, int NWV = GM_WAVES>
+__global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_valid, int K, float* part) {
     static_assert(!XT || sizeof(WT) == 2, "the tiled activation layout feeds the fp16 matrix cores");
+    static_assert(NWV == 16 || (NWV == 4 && SPLIT), "4-wave workgroups only produce split-K partials");
+    constexpr int GM_WAVES = NWV;               // shadows the namespace constant inside this kernel
     constexpr int EPL = WTraits<WT>::EPL;            // weights per 16-byte load: 4 (fp32) or 8 (fp16)
     constexpr int NLD = GM_KW / (4 * EPL);           // loads per lane and row tile: a wave-load covers 16 rows x 4*EPL k
     constexpr int XV = EPL / 4;
@@ -78,7 +83,9 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
     const int on = n0 + 16 * ot + 4 * (ol >> 4) + orr, ob = oh * 16 + (ol & 15);
     const bool active = slot < GM_R2 * NBH && on < a.N && ob < nb_valid;
     EpiPre pre{0.f, 0.f, nullptr, 0, 0, 0};
-    if (!SPLIT && active) pre = gemv_epi_prefetch<EPI>(a, on, ob);
+    if constexpr (NWV == 16) {
+        if (!SPLIT && active) pre = gemv_epi_prefetch<EPI>(a, on, ob);
+    }
 
     // keep every load above the first MFMA: without this the scheduler sinks the loads next to their uses to save
     // registers, and a wave then has a few hundred bytes in flight instead of its whole slice
@@ -157,6 +164,19 @@ __global__ __launch_bounds__(GM_THREADS) void gemv_mfma_kernel(GemvArgs a, int n
 #pragma unroll
         for (int h = 0; h < NBH; ++h) *reinterpret_cast<gm_f4*>(&red[wid][t * NBH + h][lane][0]) = acc[t][h];
     __syncthreads();
+    if constexpr (NWV != 16) {
+        // 256 threads finish the GM_R2 * NBH output tiles one after the other (raw partials only)
+#pragma unroll
+        for (int sl = 0; sl < GM_R2 * NBH; ++sl) {
+            const int t2 = sl / NBH, h2 = sl - t2 * NBH;
+            const int n2 = n0 + 16 * t2 + 4 * (ol >> 4) + orr, b2 = h2 * 16 + (ol & 15);
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NWV; ++wv) s += red[wv][sl][ol][orr];
+            if (n2 < a.N && b2 < nb_valid) part[((long long)blockIdx.y * nb_valid + b2) * a.N + n2] = s;
+        }
+        return;
+    }
     if (slot < GM_R2 * NBH) {
         float s = 0.f;
 #pragma unroll
@@ -211,6 +231,12 @@ __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const 
         for (int k = 0; k < 4; ++k) p[k] = part[((long long)k * nb_valid + b) * a.N + n];
 #pragma unroll
         for (int k = 0; k < 4; ++k) s += p[k];
+    } else if (S == 16) {  // 4-wave workgroups (last layer's fc2 in the tiled path): same idea
+        float p[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p[k] = part[((long long)k * nb_valid + b) * a.N + n];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += p[k];
     } else {
         for (int k = 0; k < S; ++k) s += part[((long long)k * nb_valid + b) * a.N + n];
     }
@@ -220,7 +246,24 @@ __global__ __launch_bounds__(ER_WG) void splitk_finish_kernel(GemvArgs a, const 
 // one pass over <= 32 rows; K = ksplit * 1536; a.W must point at the TILED copy of the matrix.  `part` must hold ksplit * nb_valid * N floats when ksplit > 1.
 // defer_finish: a split-K launch leaves its partials in `part` (the consumer - prep_rows_kernel with sk_part - finishes them)
 template <typename WT, int EPI, bool XT = false>
-inline hipError_t launch_gemv_mfma(const GemvArgs& a, int nb_valid, int K, float* part, hipStream_t st, bool defer_finish = false) {
+inline hipError_t launch_gemv_mfma(const GemvArgs& a, int nb_valid, int K, float* part, hipStream_t st, bool defer_finish = false,
+                                   bool narrow = false) {
+    if (narrow) {       // 4-wave workgroups: K / 384 K-ranges per row tile, partials only (the caller's consumer finishes them)
+        if constexpr (XT) {
+            const int ks4 = K / (4 * GM_KW);
+            if (K != ks4 * 4 * GM_KW) return hipErrorInvalidValue;
+            const dim3 grid4((a.N + GM_ROWS - 1) / GM_ROWS, ks4);
+            if (nb_valid > 16) hipLaunchKernelGGL((gemv_mfma_kernel<WT, 2, EPI, true, true, 4>), grid4, dim3(256), 0, st, a, nb_valid, K, part);
+            else hipLaunchKernelGGL((gemv_mfma_kernel<WT, 1, EPI, true, true, 4>), grid4, dim3(256), 0, st, a, nb_valid, K, part);
+            hipError_t e4 = hipGetLastError();
+            if (e4 != hipSuccess || defer_finish) return e4;
+            const long long total4 = (long long)nb_valid * a.N;
+            hipLaunchKernelGGL((splitk_finish_kernel<EPI>), dim3((unsigned)((total4 + ER_WG - 1) / ER_WG)), dim3(ER_WG), 0, st, a, part, ks4, nb_valid);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     const int ksplit = K / (GM_WAVES * GM_KW);
     if (K != ksplit * GM_WAVES * GM_KW) return hipErrorInvalidValue;
     const dim3 grid((a.N + GM_ROWS - 1) / GM_ROWS, ksplit);

@@ -114,7 +114,7 @@ def test_attention_entry_loads_its_arguments_once(kernels):
 def test_row_kernels_have_no_per_element_index_division(kernels):
     """Element-wise kernels of the per-layer prefill path take a row per block and a float4 per thread; a 64-bit index division
     per element made kv_scatter_half_kernel compute-bound (26 us per layer for 63 MB)."""
-    limits = {r"kv_scatter_half_kernel": 140, r"split_rows_f16_kernel": 140, r"splitk_finish_kernelILi2E": 200}
+    limits = {r"kv_scatter_half_kernel": 140, r"split_rows_f16_kernel": 140, r"splitk_finish_kernelILi2E": 320}      # three slice-count forms (4 and 16 unrolled, generic loop)
     for pat, lim in limits.items():
         for n, b in select(kernels, pat).items():
             assert len(b) < lim, (n, len(b))
