@@ -1000,9 +1000,13 @@ static int linear_hs(er_ctx* c, const float* A, int lda, const _Float16* W, cons
 static int linear_hs(er_ctx* c, const float* A, int lda, const _Float16* W, const float* bias, float* C, int ldc, int M, int N, int K,
                      bool relu, const float* resid, int ldr, hipStream_t st) {
     // measured (profiles/r03_prefill_fast_gemm.log): with its 64-row tiles (two A images per stage) and the extra split pass the
-    // LDS-DMA form wins for ONE prefix (encode + prefill 24.2 -> 23.1 ms) and loses to the register-staged 128 x 128 kernel from
-    // 8 prefixes on (13.4 -> 13.8 ms per sample at B = 8, 12.65 -> 13.1 at B = 32): used up to two prefixes
-    if (K % XBK != 0 || M > 4608) { HIPRET(linear_h(A, lda, W, bias, C, ldc, M, N, K, relu, resid, ldr, st)); return 0; }
+    // LDS-DMA form wins at 2050 rows (one prefix: encode + prefill 24.2 -> 23.1 ms) and loses to the register-staged 128 x 128 kernel
+    // at 16400 rows and beyond (8 prefixes: 13.4 -> 13.8 ms per sample, 32: 12.65 -> 13.1).  The rule is on ROWS - what decides is how
+    // many 64-row tiles a CU has to walk, whoever owns the rows - so one long resumed prefix (core/models.py:225-226; 14050 rows in the
+    // long-context tests) takes the register-staged kernel exactly as seven short ones would.  Both forms give the same bits
+    // (tests/test_gpu_kernels.py::test_gemm_f16s_forms_agree).
+    constexpr int HS_MAX_ROWS = 4608;          // two 2050-token prefixes + slack
+    if (K % XBK != 0 || M > HS_MAX_ROWS) { HIPRET(linear_h(A, lda, W, bias, C, ldc, M, N, K, relu, resid, ldr, st)); return 0; }
     ERCHK(ensure(c->p_hi, (size_t)M * K / 2 + 8));
     ERCHK(ensure(c->p_lo, (size_t)M * K / 2 + 8));
     _Float16* hi = reinterpret_cast<_Float16*>(c->p_hi.p);
@@ -1688,7 +1692,10 @@ extern "C" int er_k_gemm_f16s(const float* a, const void* w, const float* bias, 
     GemmArgs g = gemm_args_default();
     g.A = a; g.B = reinterpret_cast<const float*>(w); g.C = cc; g.bias = bias; g.resid = resid; g.M = m; g.N = n; g.K = k;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldc; g.relu = relu;
-    if (k % XBK == 0 && !(ldb & 7)) {      // the product path of the fast-mode prefill: split pass + LDS-DMA kernel (linear_hs)
+    // ER_K_GEMM_F16S_FORM = reg / dma pins one of the two forms linear_hs chooses between (unit tests compare them bit for bit)
+    const char* form = getenv("ER_K_GEMM_F16S_FORM");
+    const bool force_reg = form && form[0] == 'r';
+    if (k % XBK == 0 && !(ldb & 7) && !force_reg) {      // the product path of the fast-mode prefill: split pass + LDS-DMA kernel (linear_hs)
         _Float16 *hi = nullptr, *lo = nullptr;
         HIPCHK(hipMalloc(&hi, (size_t)m * k * 2));
         HIPCHK(hipMalloc(&lo, (size_t)m * k * 2));

@@ -368,6 +368,24 @@ def test_gemm_f16_split_activations(M, N, K):
     close(c2, torch.relu(ref), 2e-6 + 1e-7 * K, 2e-6, "split fp16 gemm relu")
 
 
+@pytest.mark.parametrize("M,N,K", [(2050, 4608, 1536), (2050, 1536, 6144), (300, 1536, 1536)])
+def test_gemm_f16s_forms_agree(M, N, K, monkeypatch):
+    """The fast-mode prefill picks between two forms of the split-fp16 product by row count (er_api.hip linear_hs): split pass + LDS-DMA
+    kernel for one or two prefixes, register-staged kernel beyond.  The claim that a row's logits do not depend on how many prefixes
+    share the launch rests on the two forms giving the same BITS (round-3 advisor): same hi / lo split, same MFMA order per accumulator."""
+    from edgerunner_amd import kernels as K_
+    a, w = rnd(M, K, seed=174), rnd(N, K, seed=175, scale=0.05)
+    bias, resid = rnd(N, seed=176), rnd(M, N, seed=177)
+    wh = w.half()
+    out = {}
+    for form in ("dma", "reg"):
+        monkeypatch.setenv("ER_K_GEMM_F16S_FORM", form)
+        out[form] = (K_.gemm_f16s(a, wh, bias, resid), K_.gemm_f16s(a, wh, bias, None, relu=True))
+    assert torch.equal(out["dma"][0], out["reg"][0]) and torch.equal(out["dma"][1], out["reg"][1])
+    ref = a.double() @ wh.double().T + bias.double() + resid.double()
+    close(out["reg"][0], ref, 2e-6 + 1e-7 * K, 2e-6, "register-staged split fp16 gemm")
+
+
 @pytest.mark.parametrize("B,H,N,M", [(1, 16, 2048, 2048), (2, 16, 2048, 257), (1, 2, 100, 70), (1, 1, 33, 1)])
 def test_flash_attn_f16(B, H, N, M):
     from edgerunner_amd import kernels as K_

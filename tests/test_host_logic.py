@@ -247,6 +247,20 @@ def test_clean_like_trimesh_multibody_and_reference_fixtures():
     assert len(ev) == 0 and len(ef) == 0
 
 
+def test_unbuilt_decoder_shapes_are_refused_with_the_option_names():
+    """config_defaults['default'] = Options() is hidden_dim 1024 (core/options.py:71,155-156) and ShapeOPTConfig is generic
+    (modeling_opt.py:86-134); the decode kernels stream 1536-wide rows only.  LMM says so before any device is touched."""
+    import dataclasses
+    from edgerunner_amd.models import LMM
+    from edgerunner_amd.options import config_defaults
+    with pytest.raises(NotImplementedError, match=r"hidden_dim=1024.*--hidden_dim 1536"):
+        LMM(dataclasses.replace(config_defaults["ArAE"], hidden_dim=1024), "cuda:0", precision=None)
+    with pytest.raises(NotImplementedError, match="intermediate_dim=4096"):
+        LMM(dataclasses.replace(config_defaults["ArAE"], intermediate_dim=4096), "cuda:0", precision=None)
+    with pytest.raises(NotImplementedError):
+        LMM(config_defaults["default"], "cuda:0", precision=None)          # image-conditioned, hidden 1024
+
+
 # ------------------------------------------------------------------ kernel selection rules (pure host logic behind the C ABI)
 def _plan(batch, l_cap, heads=16, head_dim=96, hidden=1536):
     from edgerunner_amd import native
