@@ -278,6 +278,14 @@ extern "C" int er_dit_encode_image(er_dit_ctx* c, const float* images, int B, in
 static hipError_t dit_ln_mod(const float* x, float* y, int rows, int rows_per_batch, const float* table, const float* tvec,
                              long long t_bstride, long long t_cstride, int shift_idx, int scale_idx, hipStream_t st,
                              _Float16* y16 = nullptr) {
+    // four rows per wave share one copy of the modulation vectors when the rows of a batch element come in whole groups of four and
+    // there are enough rows to keep >= 4 workgroups per CU (ER_DIT_LN_RPW=1: one row per wave, A/B)
+    static const bool one = [] { const char* e = getenv("ER_DIT_LN_RPW"); return e && e[0] == '1'; }();
+    if (!one && rows_per_batch % 4 == 0 && rows % 4 == 0 && rows >= 16384 / 4) {
+        hipLaunchKernelGGL((ln_modulate_rows_kernel<16, 4>), dim3((rows / 4 + ER_NWAVES - 1) / ER_NWAVES), dim3(ER_WG), 0, st, x, y, rows,
+                           rows_per_batch, table, tvec, t_bstride, t_cstride, shift_idx, scale_idx, 1e-6f, y16);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((ln_modulate_rows_kernel<16>), dim3((rows + ER_NWAVES - 1) / ER_NWAVES), dim3(ER_WG), 0, st, x, y, rows,
                        rows_per_batch, table, tvec, t_bstride, t_cstride, shift_idx, scale_idx, 1e-6f, y16);
     return hipGetLastError();

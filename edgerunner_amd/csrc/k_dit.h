@@ -11,7 +11,10 @@ namespace er {
 //   DiT out:  table = scale_shift_table [2][C], tvec = t_emb   [B][C]     (t_bstride C,  t_cstride 0)
 // One wave per row (row in registers).  In-place allowed.  y16 (optional): the same row rounded to fp16 - the A operand of the
 // Linear that follows (gemm_hh_mfma_kernel).
-template <int CPL>
+// RPW rows per wave (all of ONE batch element - the launcher guarantees RPW | rows_per_batch): the four modulation vectors of a batch
+// element are 16 KB that every row used to re-read from L2 next to its own 4 KB (round 3: 15.3 us per launch); a wave now loads them
+// once for RPW rows.  Per-row arithmetic unchanged.
+template <int CPL, int RPW = 1>
 __global__ __launch_bounds__(ER_WG) void ln_modulate_rows_kernel(const float* x, float* y, int rows, int rows_per_batch,
                                                                  const float* table, const float* tvec, long long t_bstride,
                                                                  long long t_cstride, int shift_idx, int scale_idx, float eps,
@@ -19,47 +22,54 @@ __global__ __launch_bounds__(ER_WG) void ln_modulate_rows_kernel(const float* x,
     constexpr int C = CPL * 64, V = CPL / 4;        // a lane holds V float4: columns 4 * (lane + 64 i) .. + 3 (16-byte accesses throughout)
     static_assert(CPL % 4 == 0, "row width must be a multiple of 256");
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * ER_NWAVES + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const int b = r / rows_per_batch;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long long)r * C);
+    const int r0 = (blockIdx.x * ER_NWAVES + (threadIdx.x >> 6)) * RPW;
+    if (r0 >= rows) return;
+    const int b = r0 / rows_per_batch;
     const float* tb = tvec + (long long)b * t_bstride;
-    // every load of the row goes out before the first use: x, then the four modulation operands (y may alias x and the tables are
-    // not restrict-qualified, so left in the store loop their loads would queue behind the stores of the previous column group -
-    // four dependent L2 round trips per row; round 3 measured 15.3 us per launch = 2.7 TB/s for 42 MB)
-    f32x4 v[V], sc[V], sh[V];
+    // every load goes out before the first use: the rows, then the four modulation operands (y may alias x and the tables are
+    // not restrict-qualified, so left in the store loop their loads would queue behind the stores of the previous column group)
+    f32x4 v[RPW][V], sc[V], sh[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = xr[lane + 64 * i];
+    for (int j = 0; j < RPW; ++j) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long long)min(r0 + j, rows - 1) * C);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[j][i] = xr[lane + 64 * i];
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c4 = lane + 64 * i;
         sc[i] = reinterpret_cast<const f32x4*>(table + scale_idx * C)[c4] + reinterpret_cast<const f32x4*>(tb + scale_idx * t_cstride)[c4];
         sh[i] = reinterpret_cast<const f32x4*>(table + shift_idx * C)[c4] + reinterpret_cast<const f32x4*>(tb + shift_idx * t_cstride)[c4];
     }
-    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    const float mean = wave_sum(s) / (float)C;
-    float s2 = 0.f;
+    for (int j = 0; j < RPW; ++j) {
+        const int r = r0 + j;
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-        const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
-        s2 = fmaf(d0, d0, s2); s2 = fmaf(d1, d1, s2); s2 = fmaf(d2, d2, s2); s2 = fmaf(d3, d3, s2);
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)C + eps);
-    f32x4* yr = reinterpret_cast<f32x4*>(y + (long long)r * C);
+        for (int i = 0; i < V; ++i) s += (v[j][i].x + v[j][i].y) + (v[j][i].z + v[j][i].w);
+        const float mean = wave_sum(s) / (float)C;
+        float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-        const int c4 = lane + 64 * i;
-        f32x4 o;
-        o.x = (v[i].x - mean) * rstd * (1.0f + sc[i].x) + sh[i].x;
-        o.y = (v[i].y - mean) * rstd * (1.0f + sc[i].y) + sh[i].y;
-        o.z = (v[i].z - mean) * rstd * (1.0f + sc[i].z) + sh[i].z;
-        o.w = (v[i].w - mean) * rstd * (1.0f + sc[i].w) + sh[i].w;
-        yr[c4] = o;
-        if (y16) {
-            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-            reinterpret_cast<h4*>(y16 + (long long)r * C)[c4] = (h4){(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+        for (int i = 0; i < V; ++i) {
+            const float d0 = v[j][i].x - mean, d1 = v[j][i].y - mean, d2 = v[j][i].z - mean, d3 = v[j][i].w - mean;
+            s2 = fmaf(d0, d0, s2); s2 = fmaf(d1, d1, s2); s2 = fmaf(d2, d2, s2); s2 = fmaf(d3, d3, s2);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)C + eps);
+        if (r >= rows) continue;                     // wave-uniform (only when RPW does not divide rows: the launcher avoids it)
+        f32x4* yr = reinterpret_cast<f32x4*>(y + (long long)r * C);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c4 = lane + 64 * i;
+            f32x4 o;
+            o.x = (v[j][i].x - mean) * rstd * (1.0f + sc[i].x) + sh[i].x;
+            o.y = (v[j][i].y - mean) * rstd * (1.0f + sc[i].y) + sh[i].y;
+            o.z = (v[j][i].z - mean) * rstd * (1.0f + sc[i].z) + sh[i].z;
+            o.w = (v[j][i].w - mean) * rstd * (1.0f + sc[i].w) + sh[i].w;
+            yr[c4] = o;
+            if (y16) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                reinterpret_cast<h4*>(y16 + (long long)r * C)[c4] = (h4){(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+            }
         }
     }
 }

@@ -104,22 +104,23 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f16_kernel(FlashArgs a) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    st[kb][r] *= sl2;                // log2 units: exp(x) = exp2(x log2 e)
-                    mloc = fmaxf(mloc, st[kb][r]);
-                }
+                for (int r = 0; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, st[kb][r]), st[kb][r + 1]);      // RAW scores (v_max3_f32); scaled below
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float s = key < a.M ? st[kb][r] * sl2 : -INFINITY;
+                    const float s = key < a.M ? st[kb][r] : -INFINITY;
                     st[kb][r] = s;
                     mloc = fmaxf(mloc, s);
                 }
         }
-        mloc = xor_max<32>(mloc);
+        // log2 units: exp(x * scale) = exp2(x * sl2).  The maximum is taken over the raw scores (sl2 > 0) and every probability is ONE
+        // fma + exp2: exp2(fma(s, sl2, -m)) - round 3 spent a multiply and a subtract per score here, and this VALU loop, not the 16
+        // MFMAs of a key tile, bounds the kernel at head_dim 64.  (Packed v_pk_fma_f32 / v_pk_add_f32 forms of the same loop and
+        // a zero C operand instead of clearing the score registers measured no different on the same box: profiles/r04_dit_softmax_ab.log)
+        mloc = xor_max<32>(mloc) * sl2;
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // m_run = -inf on the first tile -> 0
         float psum = 0.f;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_f16_kernel(FlashArgs a) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);  // masked keys: exp2(-inf) = 0
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[kb][r], sl2, -m_new));  // masked keys: exp2(-inf) = 0
                 st[kb][r] = p;
                 psum += p;
             }
@@ -304,22 +305,19 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    st[kb][r] *= sl2;                // log2 units: exp(x) = exp2(x log2 e)
-                    mloc = fmaxf(mloc, st[kb][r]);
-                }
+                for (int r = 0; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, st[kb][r]), st[kb][r + 1]);      // RAW scores (v_max3_f32); scaled below
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float s = key < a.M ? st[kb][r] * sl2 : -INFINITY;
+                    const float s = key < a.M ? st[kb][r] : -INFINITY;
                     st[kb][r] = s;
                     mloc = fmaxf(mloc, s);
                 }
         }
-        mloc = xor_max<32>(mloc);
+        mloc = xor_max<32>(mloc) * sl2;
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[kb][r], sl2, -m_new));
                 st[kb][r] = p;
                 psum += p;
             }

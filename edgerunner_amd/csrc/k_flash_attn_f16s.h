@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f16s_kernel(Flash32Args a
     const int ntiles = (kmax + KT - 1) / KT;
     const int wave_last_key = CAUSAL ? (q0 + 31 + a.causal_off) : (a.M - 1);
     const float sdiv = a.sqrt_d * FAS_QSCALE;
+    const float inv_sdiv = 1.0f / sdiv;
 
     constexpr int NST = (KT * F4) / THREADS;
     static_assert((KT * F4) % THREADS == 0, "staging loop shape");
@@ -133,7 +134,10 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f16s_kernel(Flash32Args a
                 const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 bool ok = key < a.M;
                 if (CAUSAL) ok = ok && key <= qi + a.causal_off;
-                const float s = ok ? st[kb][r] / sdiv : -INFINITY;
+                // the correctly rounded quotient in three instructions (see k_flash_attn_f32.h; sdiv is sqrt(D) times a power of two,
+                // so the exhaustive check of scripts/probes/div_const_probe.hip carries over)
+                const float q0 = st[kb][r] * inv_sdiv;
+                const float s = ok ? fmaf(fmaf(-q0, sdiv, st[kb][r]), inv_sdiv, q0) : -INFINITY;
                 st[kb][r] = s;
                 mloc = fmaxf(mloc, s);
             }

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[db][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;    // l_run covers this lane half's keys only
+    const float inv_sqrt_d = 1.0f / a.sqrt_d;  // one true division per thread
 
     // keys any query of this WORKGROUP can see
     const int wg_last_q = min(a.N - 1, qt * (NWV * FA32_QW) + NWV * FA32_QW - 1);
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
                 const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 bool ok = key < a.M;
                 if (CAUSAL) ok = ok && key <= qi + a.causal_off;
-                const float s = ok ? st[kb][r] / a.sqrt_d : -INFINITY;
+                // x / sqrt(D) as the reference computes it (attention.py:52), in three instructions instead of hipcc's ten-instruction
+                // division: q0 = x * y, r = fma(-q0, c, x), q = fma(r, y, q0) with y = 1 / c is the correctly rounded quotient for every
+                // |x| in [1e-30, 1e30] - checked over all 2^32 inputs for c = sqrtf(96) and 8 (scripts/probes/div_const_probe.hip,
+                // profiles/r04_div_const_probe.log); 32 divisions per lane and key tile were a third of this loop's VALU work
+                const float q0 = st[kb][r] * inv_sqrt_d;
+                const float s = ok ? fmaf(fmaf(-q0, a.sqrt_d, st[kb][r]), inv_sqrt_d, q0) : -INFINITY;
                 st[kb][r] = s;
                 mloc = fmaxf(mloc, s);
             }

@@ -290,11 +290,11 @@ def test_streaming_batched_attention_ids(gold_small, monkeypatch, precision):
     assert_ids(toks[1], toks[16], "rows 1 and 16 hold the same cloud")
 
 
-@pytest.mark.parametrize("B", [12, 18, 40])
+@pytest.mark.parametrize("B", [6, 12, 18, 40])
 def test_tiled_activation_path_matches_row_major_path(B, monkeypatch):
     """Fast-mode batches on the matrix cores (round 4): activations in the tiled hi | lo operand layout, out_proj / fc2 as 4-wave split-K
     workgroups finished by the next LayerNorm launch.  Against the round-3 launch sequence (ER_XT=0: row-major fp32 inputs): greedy ids
-    identical, teacher-forced logits equal to fp32 round-off (the split-K partial sums associate differently).  B = 12: split attention
+    identical, teacher-forced logits equal to fp32 round-off (the split-K partial sums associate differently).  B = 6: out_proj on the one-pass VALU kernel, 12: split attention
     (out_proj stays row-major), 18: streaming attention, 40: two row groups, the second one partial."""
     toks, logits = {}, {}
     batch = torch.cat([cloud(i) for i in range(B)])
@@ -812,7 +812,9 @@ def test_config2_shape_sample_mode_distributions(gold_batch):
             k = min(10, len(allowed))
             mine = torch.topk(s, k)
             if set(mine.indices.tolist()) != set(gi[:k].tolist()):
-                assert k == 10 and abs(float(gv[9] - gv[10])) < 2e-3, (r, t, mine.indices.tolist(), gi.tolist())
+                # a swap of the 10th / 11th candidate is only legitimate inside the logit error of the path itself: the batched fast
+                # mode is within ~1.1e-5 of the emulation (test above), so the gap must be below 1e-4 (round 3 allowed 2e-3)
+                assert k == 10 and abs(float(gv[9] - gv[10])) < 1e-4, (r, t, mine.indices.tolist(), gi.tolist())
                 swaps += 1
             else:
                 p_ref = torch.softmax(torch.from_numpy(gv[:k].astype(np.float64)), 0).numpy()
