@@ -635,6 +635,18 @@ def test_boundary_errors_are_loud():
     empty = LMM(dataclasses.replace(config_defaults["ArAE"], num_layers=1), DEV)
     with pytest.raises(native.NativeError, match="never loaded"):
         empty.encode_cond(cloud(0, 64), [1000])
+    # after release_checkpoint() the weights live only in the native context: a context that was closed cannot silently come back empty
+    from edgerunner_amd import weights as W
+    opt1 = dataclasses.replace(config_defaults["ArAE"], num_layers=1)
+    rel = LMM(opt1, DEV, precision=None)
+    rel.load_state_dict(W.make_state_dict(opt1, 0, "perturbed"), strict=True)
+    rel.release_checkpoint()
+    with pytest.raises(native.NativeError, match="cannot be"):
+        rel.half()
+    rel._dec.close()
+    rel._dec = None
+    with pytest.raises(native.NativeError, match="released"):
+        _ = rel.mesh_decoder
     # an unbuilt decoder shape is refused by LMM with the option names (round 4), and by er_create for a direct caller of the C ABI
     with pytest.raises(NotImplementedError, match="hidden_dim=1024"):
         LMM(dataclasses.replace(config_defaults["ArAE"], hidden_dim=1024, num_layers=1), DEV)
