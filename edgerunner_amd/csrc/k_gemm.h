@@ -718,6 +718,96 @@ __global__ __launch_bounds__(ER_WG) void cvt_f16_rows_f32_kernel(const _Float16*
     for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < n; i += (long long)gridDim.x * ER_WG) y[i] = (float)x[i];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Exact fp32 GEMM with both operands by LDS-DMA (round 4): C = epilogue(A[M,K] . W[N,K]^T), v_mfma_f32_32x32x2_f32, for the plain
+// (NT, unbatched, K % 32 == 0) Linears of the exact-mode prefill and point encoder.  gemm_f32_mfma_kernel above stages a k-tile through
+// registers and scatters it k-major into LDS (8 + 8 four-byte ds_write per thread and tile, one wave per SIMD busy with that while the
+// matrix pipe idles): 0.53 of the fp32 matrix peak on the prefill shapes.  A 32-float row of a k-tile is 128 bytes - exactly the row
+// image of the fp16 LDS-DMA kernel (gemm_hh_mfma_kernel): 8 chunks of 16 B, chunk c of row r stored at slot c ^ ((r >> 1) & 7), written
+// by `global_load_lds_dwordx4` with no registers and no ds_write.  The fp32 matrix core is 16x slower than the fp16 one, so a 32-deep
+// k-tile is 4096 MFMA cycles per wave and the next tile's DMA lands long before it is needed: two stages, one barrier per k-tile.
+// Operand fetch: ONE ds_read_b32 per MFMA and operand block, lane (row l & 31, k = 2 kk + (l >> 5)) - the same (lane half -> k) assignment
+// and the same k order per accumulator as gemm_f32_mfma_kernel: BIT-IDENTICAL results (tests/test_gpu_kernels.py::test_gemm_f32_lds_dma).
+template <int TM, int TN>
+__global__ __launch_bounds__(ER_WG) void gemm_f32d_mfma_kernel(GemmArgs g, int ntx) {
+    constexpr int GBM = 64 * TM, GBN = 64 * TN, FBK = 32;                        // k-tile: 32 floats = one 128-byte row image
+    constexpr int STAGE = (GBM + GBN) * FBK;                                     // floats per stage
+    constexpr int NAI = GBM / 32, NBI = GBN / 32;                                // 8-row LDS-DMA pieces per wave and operand
+    static_assert(2 * STAGE * 4 <= 65536, "two stages fit the static LDS limit");
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];                // the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + within;      // XCD-aware tile order (bijective)
+    const int ty = lin / ntx, tx = lin - ty * ntx;
+    const int m0 = ty * GBM, n0 = tx * GBN;
+    const int nk = g.K / FBK;
+    // (Measured and not kept, profiles/r04_gemm_f32d_ab.log: skipping the MFMAs of 32-row blocks that lie outside the matrix and running
+    // the ragged last row tile first - the prefill's 2050 rows are 16 full 128-row tiles + 2 rows, i.e. 3.19 tiles per CU - made encode +
+    // prefill SLOWER on the same box, 42.7 -> 44.9 ms.)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const float* pa[NAI];
+    const float* pb[NBI];
+#pragma unroll
+    for (int j = 0; j < NAI; ++j) {
+        const int r = 8 * (wid * NAI + j) + lrow;
+        pa[j] = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + ((lslot ^ ((r >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int j = 0; j < NBI; ++j) {
+        const int r = 8 * (wid * NBI + j) + lrow;
+        pb[j] = g.B + (long long)min(n0 + r, g.N - 1) * g.ldb + ((lslot ^ ((r >> 1) & 7)) << 2);
+    }
+    auto issue = [&](int kt, int s) {
+        float* as = lds + s * STAGE;
+        float* bs = as + GBM * FBK;
+#pragma unroll
+        for (int j = 0; j < NAI; ++j)
+            __builtin_amdgcn_global_load_lds((er_gptr)(pa[j] + kt * FBK), (er_lptr)(as + 8 * (wid * NAI + j) * FBK), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NBI; ++j)
+            __builtin_amdgcn_global_load_lds((er_gptr)(pb[j] + kt * FBK), (er_lptr)(bs + 8 * (wid * NBI + j) * FBK), 16, 0, 0);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int kh = lane >> 5, li = lane & 31;
+    // float index of (row, k) inside a tile image: row * 32 + ((k >> 2) ^ ((row >> 1) & 7)) * 4 + (k & 3); the rows this lane reads
+    // are wm * 32 TM + 32 i + li: (row >> 1) & 7 = (li >> 1) & 7 for every i (32 i and wm * 32 TM are multiples of 16 rows)
+    const int swz = (li >> 1) & 7;
+    if (nk > 0) issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);      // lands while this tile is multiplied (4096 MFMA cycles per wave)
+        const float* as = lds + cur * STAGE + (wm * 32 * TM + li) * FBK;
+        const float* bs = lds + cur * STAGE + GBM * FBK + (wn * 32 * TN + li) * FBK;
+#pragma unroll
+        for (int kk = 0; kk < FBK / 2; ++kk) {
+            const int k = 2 * kk + kh;                                          // kh is 0 / 1: the chunk index is uniform per lane half
+            const int off = (((k >> 2) ^ swz) << 2) + (k & 3);
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = as[32 * i * FBK + off];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = bs[32 * j * FBK + off];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN>(g, g.C, acc, m0, n0, wm, wn, kh, li);
+}
+
 inline int gemm_pick_tile(int M, int N, int batch);
 inline GemmArgs gemm_args_default() {
     GemmArgs g{};
@@ -733,7 +823,8 @@ inline GemmArgs gemm_args_default() {
 // forces a shape for A/B runs.
 constexpr int GEMM_MIN_WGS_PER_CU = 3;
 inline int gemm_pick_tile(int M, int N, int batch) {
-    static const int forced = [] { const char* v = getenv("ER_GEMM_TILE"); return v ? atoi(v) : 0; }();
+    const char* fv = getenv("ER_GEMM_TILE");            // per call: the unit tests force each shape in one process
+    const int forced = fv ? atoi(fv) : 0;
     if (forced >= 1 && forced <= 3) return forced;
     auto wgs = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     const long long want = 256LL * GEMM_MIN_WGS_PER_CU;
@@ -846,7 +937,24 @@ inline hipError_t launch_gemm_f16s(const GemmArgs& g, hipStream_t st) {  // NT o
     return hipGetLastError();
 }
 
+// the plain NT products (no batch, no causal bound, K-major B) with K % 32 == 0 and 16-byte aligned rows take the LDS-DMA kernel;
+// ER_GEMM_F32_DMA=0 keeps the register-staged kernel everywhere (A/B, parity matrix: the two give the same bits)
+inline bool gemm_f32_dma_ok(const GemmArgs& g, int batch) {
+    const char* e = getenv("ER_GEMM_F32_DMA");       // read per launch (a few dozen launches per prefill): the unit test flips it in-process
+    const bool off = e && e[0] == '0';
+    return !off && batch == 1 && !g.b_is_kn && !g.causal && g.K % 32 == 0 && !(g.lda & 3) && !(g.ldb & 3) &&
+           !((reinterpret_cast<unsigned long long>(g.A) | reinterpret_cast<unsigned long long>(g.B)) & 15);
+}
 inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+    if (gemm_f32_dma_ok(g, batch)) {
+        const int tile = gemm_pick_tile(g.M, g.N, 1);
+        const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
+        const int ntx = (g.N + bn - 1) / bn, nty = (g.M + bm - 1) / bm;
+        if (tile == 1) hipLaunchKernelGGL((gemm_f32d_mfma_kernel<2, 2>), dim3(ntx * nty), dim3(ER_WG), 0, st, g, ntx);
+        else if (tile == 2) hipLaunchKernelGGL((gemm_f32d_mfma_kernel<1, 2>), dim3(ntx * nty), dim3(ER_WG), 0, st, g, ntx);
+        else hipLaunchKernelGGL((gemm_f32d_mfma_kernel<1, 1>), dim3(ntx * nty), dim3(ER_WG), 0, st, g, ntx);
+        return hipGetLastError();
+    }
     ER_GEMM_DISPATCH(ER_K_F32, g, batch, st);
     return hipGetLastError();
 }

@@ -286,6 +286,28 @@ def test_gemm_scale_div():
     close(c, ref, 1e-5, 1e-5, "scores / sqrt(D)")
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(2050, 4608, 1536, 0), (2050, 1536, 6144, 0), (2050, 6144, 1536, 1), (2048, 1024, 8192, 2),
+                                          (300, 1536, 1536, 3), (77, 200, 64, 0), (1, 96, 32, 0)])
+def test_gemm_f32_lds_dma(M, N, K, tile, monkeypatch):
+    """Exact-mode prefill / encoder Linears on the LDS-DMA fp32 kernel (round 4) against the register-staged kernel they replaced: the
+    same (lane half -> k) assignment and k order per accumulator, so the results must agree BIT FOR BIT (bias, ReLU, residual epilogues;
+    ragged M / N; every tile shape), and both must match float64 to the fp32 chain's round-off."""
+    from edgerunner_amd import kernels as K_
+    a, w = rnd(M, K, seed=270), rnd(N, K, seed=271, scale=0.05)
+    bias, resid = rnd(N, seed=272), rnd(M, N, seed=273)
+    if tile:
+        monkeypatch.setenv("ER_GEMM_TILE", str(tile))
+    out = {}
+    for dma in ("0", "1"):
+        monkeypatch.setenv("ER_GEMM_F32_DMA", dma)
+        out[dma] = (K_.gemm(a, w, bias, resid), K_.gemm(a, w, bias, None, relu=True), K_.gemm(a, w))
+    for x, y in zip(out["0"], out["1"]):
+        assert torch.equal(x, y), f"LDS-DMA fp32 GEMM differs from the register-staged one: max {float((x - y).abs().max()):.3e}"
+    ref = a.double() @ w.double().T
+    close(out["1"][2], ref, 2e-6 + 1e-7 * K, 1e-5, "fp32 LDS-DMA gemm")
+    close(out["1"][0], ref + bias.double() + resid.double(), 2e-6 + 1e-7 * K, 1e-5, "fp32 LDS-DMA gemm + bias + resid")
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (4096, 1024, 1024), (514, 3072, 1024), (257, 1280, 5120), (77, 200, 608)])
 def test_gemm_f16_input_mfma(M, N, K):
     """fp16-input MFMA GEMM == fp32 math on fp16-rounded operands (asymmetric operands catch a transposed map)."""
