@@ -35,6 +35,8 @@ def _worker(rank, world, port, n_items, q):
     full = D.gather_token_streams([_stream(i) for i in mine], n_items)
     ok = len(full) == n_items and all(np.array_equal(full[i], _stream(i)) for i in range(n_items))
     t = D.max_over_ranks(float(rank + 1))
+    by_rank = D.all_ranks(10.0 * rank + 0.5)              # bench.py's per-rank diagnostics: every rank sees every rank's value, in rank order
+    ok = ok and by_rank == [10.0 * r_ + 0.5 for r_ in range(world)]
     D.barrier()
     q.put((rank, bool(ok), t))
     torch.distributed.destroy_process_group()

@@ -208,6 +208,32 @@ def test_clean_like_trimesh_merge_unique_and_winding():
     assert mv.tolist() == [[3.0, 0, 0], [1.0, 0, 0], [2.0, 0, 0], [0.5, 1, 0]] and mf.tolist() == [[0, 1, 2], [1, 0, 3]]
 
 
+def test_merge_vertices_properties_on_random_soups():
+    """merge_vertices (trimesh 4.0.5 restated): idempotent, geometry-preserving (every face keeps its three corner positions), survivors in
+    first-occurrence order, unreferenced vertices dropped - on random triangle soups with duplicated corners."""
+    from edgerunner_amd import meto
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        base = rng.integers(0, 6, size=(int(rng.integers(4, 30)), 3)).astype(np.float64) / 5.0     # few distinct positions -> many duplicates
+        nf = int(rng.integers(1, 40))
+        faces = rng.integers(0, len(base), size=(nf, 3))
+        verts = np.vstack([base, rng.random((3, 3)) + 7.0])                                            # three unreferenced vertices
+        mv, mf = meto.merge_vertices(verts, faces)
+        assert np.array_equal(mv[mf], verts[faces])                                                    # geometry of every face unchanged
+        assert len(np.unique(np.round(mv * 1e8).astype(np.int64), axis=0)) == len(mv)                  # no duplicate survivors
+        assert not (mv > 6.0).any()                                                                    # unreferenced ones are gone
+        # first-occurrence order: scanning the ORIGINAL vertices in index order, a position is appended when a referenced vertex shows it first
+        seen, order = set(), []
+        ref = set(faces.reshape(-1).tolist())
+        for i, vtx in enumerate(verts):
+            key = tuple(np.round(vtx * 1e8).astype(np.int64).tolist())
+            if i in ref and key not in seen:
+                seen.add(key); order.append(vtx)
+        assert np.array_equal(mv, np.asarray(order))
+        mv2, mf2 = meto.merge_vertices(mv, mf)
+        assert np.array_equal(mv2, mv) and np.array_equal(mf2, mf)                                      # idempotent
+
+
 def test_mesh_object_exports_like_the_reference_callers_expect(tmp_path):
     """LMM.generate returns objects with .vertices / .faces / .export(path) (what infer.py:120 uses of trimesh.Trimesh);
     they still unpack as (vertices, faces)."""
