@@ -947,7 +947,13 @@ inline bool gemm_f32_dma_ok(const GemmArgs& g, int batch) {
 }
 inline hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     if (gemm_f32_dma_ok(g, batch)) {
-        const int tile = gemm_pick_tile(g.M, g.N, 1);
+        // tile rule of the LDS-DMA kernel: it is MFMA-bound per tile, so what matters is the number of ROUNDS the CUs need - a 2050 x 6144
+        // product is 816 tiles of 128 x 128 = 3.19 per CU, i.e. FOUR rounds on 48 CUs, against 1584 tiles of 64 x 128 = 6.19 -> seven half-size
+        // rounds (3.5): the big tile is kept only from ER_GEMM_F32D_MIN128 (default 4) tiles per CU on.  Any shape gives the same bits.
+        const char* mv = getenv("ER_GEMM_F32D_MIN128");
+        const long long min128 = 256LL * (mv ? atoi(mv) : 4);
+        int tile = gemm_pick_tile(g.M, g.N, 1);
+        if (!getenv("ER_GEMM_TILE") && tile == 1 && (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) < min128) tile = 2;
         const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
         const int ntx = (g.N + bn - 1) / bn, nty = (g.M + bm - 1) / bm;
         if (tile == 1) hipLaunchKernelGGL((gemm_f32d_mfma_kernel<2, 2>), dim3(ntx * nty), dim3(ER_WG), 0, st, g, ntx);
