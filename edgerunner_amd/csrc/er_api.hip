@@ -1167,6 +1167,31 @@ extern "C" int er_embed_tokens(er_ctx* c, const int32_t* ids, int B, int R, floa
 }
 
 // ------------------------------------------------------------------------------------ prefill
+// Ragged last row tile of the exact prefill (ER_PREFILL_TAIL=0 switches it off): 2050 prefix rows are 32 row tiles of 64
+// plus TWO rows, and those two rows cost out_proj / fc2 a fourth round of tiles on 24 CUs (792 tiles of 64 x 64 = 3.09 per CU) and
+// fc1 a seventh half round (1584 tiles of 64 x 128 = 6.19 per CU): encode + prefill 42.2 -> 38.2 ms on the same box
+// (profiles/r04_prefill_tail.log).  The out_proj / fc1 / fc2 Linears run on the
+// first M - M % 64 rows and the 1..8 left-over rows go through the decode step's own fp32 GEMV kernels (one pass over the matrix,
+// 5..6 us), whenever that saves a round of 64-row tiles.  Rows are independent in a Linear, so the split needs no sample boundary.
+static int prefill_tail_rows(const er_ctx* c, int M) {
+    const char* v = getenv("ER_PREFILL_TAIL");
+    if ((v && atoi(v) == 0) || c->fast) return 0;
+    if (c->cfg.hidden_dim != 1536 || c->cfg.intermediate_dim != 6144) return 0;      // the GEMV kernels are built for these K
+    const int tail = M % 64;
+    if (tail < 1 || tail > 8 || M < 1024) return 0;
+    const long long nt = c->cfg.hidden_dim / 64;
+    const long long r_all = ((long long)(M / 64 + 1) * nt + 255) / 256, r_main = ((long long)(M / 64) * nt + 255) / 256;
+    return r_all > r_main ? tail : 0;
+}
+// C[tail rows] = epilogue(A . W^T): dense rows (lda == K, ldc == ldr == N) behind the GEMM's main part
+template <int KS, int RW, int EPI>
+static hipError_t linear_tail(const float* A, const float* W, const float* bias, float* C, const float* resid, int rows, int N, int K,
+                              hipStream_t st) {
+    GemvArgs t{};
+    t.W = W; t.bias = bias; t.N = N; t.xin = A; t.out = C; t.resid = resid;
+    return gemv_groups<float, KS, RW, PRO_NONE, EPI>(t, rows, K, st);
+}
+
 extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* stream) {
     if (!c || !embeds || B <= 0 || S <= 0) return fail(ER_ERR_INVALID, "er_prefill: bad argument");
     ERCHK(er_finalize_weights(c));
@@ -1184,6 +1209,7 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
     ERCHK(ensure(c->p_y, (size_t)M * H));
     ERCHK(ensure(c->p_f, (size_t)M * I));
     float *h = c->p_h.p, *q = c->p_q.p, *a = c->p_a.p, *y = c->p_y.p, *f = c->p_f.p;
+    const int tail = prefill_tail_rows(c, M), Mm = M - tail;
 
     // hidden = inputs_embeds + pos_embeds(0..S)                       modeling_opt.py:355-357
     hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid((long long)M * H / 4)), dim3(ER_WG), 0, st, embeds, c->posemb, h, B, S, H, 0);
@@ -1233,15 +1259,20 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
         // y = h + out_proj(a); h1 = LN1(y)                               modeling_opt.py:232, 272-274
         const bool hs = c->fast;
         if (hs) ERCHK(linear_hs(c, a, H, L.wo_h, L.bo, y, H, M, H, H, false, h, H, st));
-        else HIPRET(linear(a, H, L.wo, L.bo, y, H, M, H, H, false, h, H, st));
+        else {
+            HIPRET(linear(a, H, L.wo, L.bo, y, H, Mm, H, H, false, h, H, st));
+            if (tail) HIPRET((linear_tail<1, 1, EPI_RESID>(a + (size_t)Mm * H, L.wo, L.bo, y + (size_t)Mm * H, h + (size_t)Mm * H, tail, H, H, st)));
+        }
         HIPRET(launch_layernorm(y, L.ln1w, L.ln1b, h, M, H, H, H, g.ln_eps, st));
         // y = h1 + fc2(relu(fc1(h1))); h = LN2(y)                        modeling_opt.py:281-288
         if (hs) {
             ERCHK(linear_hs(c, h, H, L.w1_h, L.b1, f, I, M, I, H, true, nullptr, 0, st));
             ERCHK(linear_hs(c, f, I, L.w2_h, L.b2, y, H, M, H, I, false, h, H, st));
         } else {
-            HIPRET(linear(h, H, L.w1, L.b1, f, I, M, I, H, true, nullptr, 0, st));
-            HIPRET(linear(f, I, L.w2, L.b2, y, H, M, H, I, false, h, H, st));
+            HIPRET(linear(h, H, L.w1, L.b1, f, I, Mm, I, H, true, nullptr, 0, st));
+            if (tail) HIPRET((linear_tail<1, 2, EPI_RELU>(h + (size_t)Mm * H, L.w1, L.b1, f + (size_t)Mm * I, nullptr, tail, I, H, st)));
+            HIPRET(linear(f, I, L.w2, L.b2, y, H, Mm, H, I, false, h, H, st));
+            if (tail) HIPRET((linear_tail<4, 2, EPI_RESID>(f + (size_t)Mm * I, L.w2, L.b2, y + (size_t)Mm * H, h + (size_t)Mm * H, tail, H, I, st)));
         }
         if (l + 1 < g.num_layers) HIPRET(launch_layernorm(y, L.ln2w, L.ln2b, h, M, H, H, H, g.ln_eps, st));
     }

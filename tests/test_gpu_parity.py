@@ -851,6 +851,42 @@ def test_config2_shape_sample_mode_distributions(gold_batch):
     lmm.mesh_decoder.reserve(1, 4096)
 
 
+# ------------------------------------------------------------------ ragged last row tile of the exact prefill through the decode GEMV
+def test_prefill_tail_rows_through_the_decode_gemv(gold_small, gold_full, monkeypatch):
+    """er_api.hip prefill_tail_rows (default; ER_PREFILL_TAIL=0 = every row through the tiled GEMM): the 2050-row prefix's last two
+    rows - the ones the first logits come from - leave the tiled GEMM for the decode step's fp32 GEMV kernels in out_proj / fc1 /
+    fc2.  Golden ids bit for bit, logits within LOGIT_TOL, and the two paths within a few ulp of each other (and NOT identical:
+    the switch must select something)."""
+    ids = gold_small["ids_min96"][0]
+    lmm = make_lmm()
+    monkeypatch.setenv("ER_PREFILL_TAIL", "0")          # read per er_prefill call
+    base = teacher_forced_logits(lmm, cloud(0), 1000, ids, {0, 1, 40})
+    _, t0 = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
+    assert_ids(t0[0], ids, "every row through the GEMM")
+    monkeypatch.delenv("ER_PREFILL_TAIL")
+    _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
+    assert_ids(toks[0], ids, "tail rows through the GEMV")
+    got = teacher_forced_logits(lmm, cloud(0), 1000, ids, set(range(96)))
+    err = max(np.abs(got[t] - gold_small["logits_min96"][t, 0]).max() for t in range(96))
+    dpath = max(np.abs(got[t] - base[t]).max() for t in base)
+    print(f"tail through GEMV: max|dlogit| vs golden {err:.3e}, vs the all-GEMM prefill {dpath:.3e}")
+    assert err < LOGIT_TOL and 0 < dpath < 5e-5
+    # two stacked samples: 4100 rows = 64 row tiles + 4 rows (all four belong to the second sample)
+    batch = torch.cat([cloud(3), cloud(0)])
+    _, tb = lmm.generate(batch, 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
+    assert_ids(tb[1], ids, "row 1 of a 2-row batch, tail rows through the GEMV")
+    # 24 layers: the first 200 tokens of configs[1]'s golden run and its recorded logits
+    big = make_lmm(num_layers=24)
+    want = gold_full["ids"][0]
+    _, t24 = big.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=200, min_new_tokens=200)
+    assert_ids(t24[0], want[:200], "24 layers, tail rows through the GEMV")
+    steps = [int(s) for s in gold_full["logit_steps"] if int(s) < 400]
+    tf = teacher_forced_logits(big, cloud(0), 1000, want, set(steps))
+    worst = max(float(np.abs(tf[s] - gold_full["logits"][list(gold_full["logit_steps"]).index(s), 0]).max()) for s in steps)
+    print(f"24 layers, tail through GEMV: teacher-forced max|dlogit| over {len(steps)} recorded steps {worst:.3e}")
+    assert worst < LOGIT_TOL
+
+
 # ------------------------------------------------------------------ BASELINE configs[1]: full size, T = 4000
 @pytest.mark.parametrize("decode_v", ["3", "2"])
 def test_full_size_greedy_T4000_bit_exact(gold_full, manifest, monkeypatch, decode_v):
