@@ -135,3 +135,14 @@ def test_flash_attn_hh_counted_waits_and_no_scratch(kernels):
         # between the first DMA piece and the end of the loop the only vector-memory loads are the DMA pieces themselves
         loads = [l for l in b[dma[0]:dma[-1] + 1] if l.startswith("global_load") and not l.startswith("global_load_lds")]
         assert not loads, (n, loads[:3])
+
+
+def test_prefill_tail_gemvs_are_in_the_code_object(kernels):
+    """er_prefill hands the prefix's 1..8 ragged rows to gemv_kernel<float, KS, NB, RW, PRO_NONE, EPI> in groups of up to four rows
+    (er_api.hip prefill_tail_rows / linear_tail): out_proj <1, NB, 1, 0, RESID, 4>, fc1 <1, NB, 2, 0, RELU, 4>, fc2 <4, NB, 2, 0, RESID, 4>
+    for NB = 1..4, and none of them spills."""
+    for ks, rw, epi in ((1, 1, 2), (1, 2, 1), (4, 2, 2)):
+        for nb in (1, 2, 3, 4):
+            sel = select(kernels, rf"gemv_kernelIfLi{ks}ELi{nb}ELi{rw}ELi0ELi{epi}ELi4EEE")
+            for n, b in sel.items():
+                assert not [l for l in b if l.startswith("scratch_")], (n, "scratch access")
