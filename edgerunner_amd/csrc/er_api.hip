@@ -135,7 +135,7 @@ struct er_ctx {
     float last_decode_ms = 0.f;
     // scratch for prefill / encoder
     Buf p_hi, p_lo;           // fast-mode prefill: hi / lo fp16 halves of the activation a Linear is about to read (LDS-DMA GEMM, split form)
-    Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp, e_ids, e_stage;
+    Buf p_h, p_q, p_a, p_y, p_f, p_sc, p_qkv, p_ap, p_aml, e_a0, e_x, e_k, e_v, e_qln, e_q, e_sc, e_att, e_l, e_ln, e_u, e_g, e_lat, e_tmp, e_ids, e_stage;
 };
 
 constexpr int ER_MAX_BATCH = 1023;   // h_pinned holds B ints + one flag
@@ -281,7 +281,7 @@ extern "C" int er_destroy(er_ctx* c) {
     hipDeviceSynchronize();
     free_kv(c);
     for (void* p : c->owned) hipFree(p);
-    for (Buf* b : {&c->p_hi, &c->p_lo, &c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->p_qkv, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
+    for (Buf* b : {&c->p_hi, &c->p_lo, &c->p_h, &c->p_q, &c->p_a, &c->p_y, &c->p_f, &c->p_sc, &c->p_qkv, &c->p_ap, &c->p_aml, &c->e_a0, &c->e_x, &c->e_k, &c->e_v, &c->e_qln,
                    &c->e_q, &c->e_sc, &c->e_att, &c->e_l, &c->e_ln, &c->e_u, &c->e_g, &c->e_lat, &c->e_tmp, &c->e_ids, &c->e_stage})
         if (b->p) hipFree(b->p);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -1210,6 +1210,17 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
     ERCHK(ensure(c->p_f, (size_t)M * I));
     float *h = c->p_h.p, *q = c->p_q.p, *a = c->p_a.p, *y = c->p_y.p, *f = c->p_f.p;
     const int tail = prefill_tail_rows(c, M), Mm = M - tail;
+    // STAGED, off by default (ER_FLASH32_KSPLIT=1; not yet run on the GPU): the causal attention of a single prefix split over two
+    // key ranges per query tile (k_flash_attn_f32.h, KSP) - only where the launch has at most 768 two-wave workgroups, i.e. B = 1
+    bool attn_ksplit = false;
+    if (!c->fast && D == 96) {
+        const char* v = getenv("ER_FLASH32_KSPLIT");
+        if (v && atoi(v) == 1 && (long long)((S + 63) / 64) * NH * B <= 768) {
+            ERCHK(ensure(c->p_ap, flash32_part_o_floats(B, NH, S, D)));
+            ERCHK(ensure(c->p_aml, flash32_part_ml_floats(B, NH, S)));
+            attn_ksplit = true;
+        }
+    }
 
     // hidden = inputs_embeds + pos_embeds(0..S)                       modeling_opt.py:355-357
     hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid((long long)M * H / 4)), dim3(ER_WG), 0, st, embeds, c->posemb, h, B, S, H, 0);
@@ -1233,6 +1244,7 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
                 f.V = (float*)vc; f.ldv = D; f.vs_b = c->kv_bstride; f.vs_h = (long long)c->Lcap * D;
                 f.O = a; f.ldo = H; f.os_b = (long long)S * H; f.os_h = D;
                 f.N = S; f.M = S; f.sqrt_d = sqrtf((float)D); f.causal_off = 0;
+                if (attn_ksplit) { f.part_o = c->p_ap.p; f.part_ml = c->p_aml.p; }
                 HIPRET(launch_flash_attn_f32(f, D, true, NH, B, st));
             }
         } else {
@@ -1794,7 +1806,16 @@ extern "C" int er_k_flash_attn_f32(const float* q, const float* k, const float* 
     a.qs_b = (long long)N * H * D; a.os_b = a.qs_b; a.ks_b = (long long)M * H * D; a.vs_b = a.ks_b;
     a.qs_h = a.ks_h = a.vs_h = a.os_h = D;
     a.sqrt_d = sqrtf((float)D); a.causal_off = M - N;
-    HIPRET(launch_flash_attn_f32(a, D, causal != 0, H, B, (hipStream_t)stream));
+    const char* ksv = getenv("ER_FLASH32_KSPLIT");         // staged key-range split of the causal prefill shape (k_flash_attn_f32.h, KSP)
+    float *po = nullptr, *pml = nullptr;
+    if (ksv && atoi(ksv) == 1 && causal && D == 96) {
+        HIPCHK(hipMalloc(&po, flash32_part_o_floats(B, H, N, D) * 4));
+        HIPCHK(hipMalloc(&pml, flash32_part_ml_floats(B, H, N) * 4));
+        a.part_o = po; a.part_ml = pml;
+    }
+    hipError_t e = launch_flash_attn_f32(a, D, causal != 0, H, B, (hipStream_t)stream);
+    if (po) { hipStreamSynchronize((hipStream_t)stream); hipFree(po); hipFree(pml); }
+    HIPRET(e);
     return ER_OK;
 }
 

@@ -29,6 +29,10 @@ struct Flash32Args {
     long long qs_h, ks_h, vs_h, os_h;       // head strides
     float sqrt_d;                           // scores are DIVIDED by sqrt(D), as the reference does (attention.py:52)
     int causal_off;                         // CAUSAL: key j is visible to query i iff j <= i + causal_off (= M - N)
+    // key-range split (KSP instantiations, launch_flash_attn_f32): unnormalised partial outputs [2][B][H][N][D] and their
+    // (running max, sum) pairs [2][B][H][N][2]; null = one workgroup walks the whole key range of its query tile
+    float* part_o;
+    float* part_ml;
 };
 
 typedef float fa32_acc __attribute__((ext_vector_type(16)));
@@ -38,7 +42,13 @@ constexpr int FA32_KT = 64, FA32_QW = 32;   // keys per tile, queries per wave
 // the query tiles from the last (longest key range) to the first so the long workgroups start first.  NWV = 4 shares a
 // staged key tile between 128 queries; NWV = 2 re-stages it twice as often but doubles the number of workgroups, which is
 // what a single 2050-token prefill needs (17 x 16 four-wave workgroups = one per CU with nothing to overlap).
-template <int D, bool CAUSAL, int NWV>
+//
+// KSP (causal prefill of ONE sample; staged in round 4, off by default - see launch_flash_attn_f32): a single 2050-token prefix is 33 x 16
+// two-wave workgroups on 512 resident slots, and the launch lasts as long as its LONGEST workgroup - 33 key tiles for the last query
+// tile against 17.5 on average, i.e. half of the SIMD time is idle waiting for the diagonal's end.  With KSP the grid holds two
+// workgroups per query tile, each walking one half of its key tiles (at most 17) and leaving an unnormalised partial (O, m, l);
+// flash32_merge_kernel combines the two.
+template <int D, bool CAUSAL, int NWV, bool KSP = false>
 __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a) {
     constexpr int THREADS = 64 * NWV;
     constexpr int LD = D + 4;               // LDS row stride (floats), LD/4 odd -> the 16-byte K reads of a 16-lane group hit 16 distinct 4-bank slots
@@ -49,7 +59,9 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int bx = KSP ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, nqt = KSP ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int ks = KSP ? (int)(blockIdx.x & 1) : 0;
+    const int qt = CAUSAL ? nqt - 1 - bx : bx;
     const int q0 = qt * (NWV * FA32_QW) + wid * FA32_QW;
     const float* Q = a.Q + b * a.qs_b + h * a.qs_h;
     const float* K = a.K + b * a.ks_b + h * a.ks_h;
@@ -96,8 +108,14 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
             vst[u] = *reinterpret_cast<const f32x4*>(V + (long long)gk * a.ldv + 4 * c4);
         }
     };
-    if (ntiles > 0) load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
+    int t_begin = 0, t_end = ntiles;
+    if constexpr (KSP) {
+        const int hlf = (ntiles + 1) >> 1;
+        t_begin = ks * hlf;
+        t_end = min(ntiles, t_begin + hlf);
+    }
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
         const int kbase = t * FA32_KT;
         __syncthreads();                     // previous tile fully consumed
 #pragma unroll
@@ -107,7 +125,7 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
             *reinterpret_cast<f32x4*>(&Vs[key * LD + 4 * c4]) = vst[u];
         }
         __syncthreads();
-        if (t + 1 < ntiles) load_tile(t + 1);
+        if (t + 1 < t_end) load_tile(t + 1);
         if (kbase > wave_last_key) continue;   // wave-uniform: the barriers above are still hit by every wave
 
         // S^T = K Q^T: two 32-key blocks; lane (li, half) holds keys kbase + kb*32 + (r&3) + 8*(r>>2) + 4*half
@@ -176,6 +194,22 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
             }
     }
     const float l_tot = xor_sum<32>(l_run);
+    if constexpr (KSP) {
+        // partial of this key range: O^T as accumulated (relative to m_run), m_run (the same in both lane halves) and the sum
+        if (qi < a.N) {
+            const long long row = (((long long)ks * gridDim.z + b) * gridDim.y + h) * a.N + qi;
+            float* prow = a.part_o + row * D;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) prow[db * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = ot[db][r];
+            if (half == 0) {
+                a.part_ml[2 * row] = m_run;
+                a.part_ml[2 * row + 1] = l_tot;
+            }
+        }
+        return;
+    }
     if (qi < a.N) {
         float* orow = O + (long long)qi * a.ldo;
 #pragma unroll
@@ -185,12 +219,51 @@ __global__ __launch_bounds__(64 * NWV) void flash_attn_f32_kernel(Flash32Args a)
     }
 }
 
+// O[b][q][h][:] = (O0 w0 + O1 w1) / (l0 w0 + l1 w1), w_i = exp(m_i - max(m0, m1)) (0 for an empty key range: m_i = -inf, l_i = 0);
+// every causal query sees at least its own key, so the denominator is never 0.  One thread per four output floats.
+__global__ __launch_bounds__(ER_WG) void flash32_merge_kernel(Flash32Args a, int D, int H, int B) {
+    const int d4n = D / 4;
+    const long long total = (long long)B * H * a.N * d4n, half_rows = (long long)B * H * a.N;
+    for (long long i = (long long)blockIdx.x * ER_WG + threadIdx.x; i < total; i += (long long)gridDim.x * ER_WG) {
+        const long long row = i / d4n;                 // (b * H + h) * N + q
+        const int c4 = (int)(i - row * d4n);
+        const int q = (int)(row % a.N);
+        const long long bh = row / a.N;
+        const int h = (int)(bh % H), b = (int)(bh / H);
+        const float m0 = a.part_ml[2 * row], l0 = a.part_ml[2 * row + 1];
+        const float m1 = a.part_ml[2 * (half_rows + row)], l1 = a.part_ml[2 * (half_rows + row) + 1];
+        const float m = fmaxf(m0, m1);
+        const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - m), w1 = (m1 == -INFINITY) ? 0.f : expf(m1 - m);
+        const float den = l0 * w0 + l1 * w1;
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(a.part_o + row * D + 4 * c4);
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(a.part_o + (half_rows + row) * D + 4 * c4);
+        f32x4 o;
+        o.x = (o0.x * w0 + o1.x * w1) / den; o.y = (o0.y * w0 + o1.y * w1) / den;
+        o.z = (o0.z * w0 + o1.z * w1) / den; o.w = (o0.w * w0 + o1.w * w1) / den;
+        *reinterpret_cast<f32x4*>(a.O + b * a.os_b + h * a.os_h + (long long)q * a.ldo + 4 * c4) = o;
+    }
+}
+// floats of the two partial buffers a key-split launch needs
+inline size_t flash32_part_o_floats(int B, int H, int N, int D) { return (size_t)2 * B * H * N * D; }
+inline size_t flash32_part_ml_floats(int B, int H, int N) { return (size_t)4 * B * H * N; }
+
 inline hipError_t launch_flash_attn_f32(const Flash32Args& a, int D, bool causal, int H, int B, hipStream_t st) {
     // two-wave workgroups while four-wave ones would leave fewer than three per CU (ER_FLASH32_NWV = 2 / 4 forces one)
     static const int forced = [] { const char* v = getenv("ER_FLASH32_NWV"); return v ? atoi(v) : 0; }();
     const long long wg4 = (long long)((a.N + 4 * FA32_QW - 1) / (4 * FA32_QW)) * H * B;
     const int nwv = (forced == 2 || forced == 4) ? forced : (wg4 < 768 ? 2 : 4);
     dim3 grid((a.N + nwv * FA32_QW - 1) / (nwv * FA32_QW), H, B), blk(64 * nwv);
+    // key-range split: only when the caller supplies the partial buffers (er_prefill / er_k_flash_attn_f32 under ER_FLASH32_KSPLIT=1 -
+    // staged, not yet measured on the GPU) and the launch is the single-sample causal prefill shape the split is for
+    if (a.part_o && a.part_ml && causal && D == 96 && nwv == 2 && (a.ldo & 3) == 0 && (a.os_b & 3) == 0 && (a.os_h & 3) == 0) {
+        grid.x *= 2;
+        hipLaunchKernelGGL((flash_attn_f32_kernel<96, true, 2, true>), grid, blk, 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const long long total = (long long)B * H * a.N * (D / 4), blocks = (total + ER_WG - 1) / ER_WG;
+        hipLaunchKernelGGL(flash32_merge_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(ER_WG), 0, st, a, D, H, B);
+        return hipGetLastError();
+    }
     if (nwv == 4) {
         if (D == 96 && causal) hipLaunchKernelGGL((flash_attn_f32_kernel<96, true, 4>), grid, blk, 0, st, a);
         else if (D == 96) hipLaunchKernelGGL((flash_attn_f32_kernel<96, false, 4>), grid, blk, 0, st, a);

@@ -887,6 +887,27 @@ def test_prefill_tail_rows_through_the_decode_gemv(gold_small, gold_full, monkey
     assert worst < LOGIT_TOL
 
 
+@pytest.mark.skipif(os.environ.get("ER_TEST_CANDIDATES") != "1", reason="staged candidate: set ER_TEST_CANDIDATES=1")
+def test_candidate_prefill_attention_key_range_split(gold_small, gold_full, monkeypatch):
+    """ER_FLASH32_KSPLIT=1 (staged, off by default): the single-sample exact prefill with its causal attention split over two key
+    ranges per query tile.  Golden ids bit for bit, logits within LOGIT_TOL, a few ulp from the unsplit prefill."""
+    ids = gold_small["ids_min96"][0]
+    lmm = make_lmm()
+    base = teacher_forced_logits(lmm, cloud(0), 1000, ids, {0, 1, 40})
+    monkeypatch.setenv("ER_FLASH32_KSPLIT", "1")          # read per er_prefill call
+    _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
+    assert_ids(toks[0], ids, "prefill attention split over key ranges")
+    got = teacher_forced_logits(lmm, cloud(0), 1000, ids, set(range(96)))
+    err = max(np.abs(got[t] - gold_small["logits_min96"][t, 0]).max() for t in range(96))
+    dpath = max(np.abs(got[t] - base[t]).max() for t in base)
+    print(f"key-range split: max|dlogit| vs golden {err:.3e}, vs the unsplit prefill {dpath:.3e}")
+    assert err < LOGIT_TOL and 0 < dpath < 5e-5
+    big = make_lmm(num_layers=24)
+    want = gold_full["ids"][0]
+    _, t24 = big.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=200, min_new_tokens=200)
+    assert_ids(t24[0], want[:200], "24 layers, prefill attention split over key ranges")
+
+
 # ------------------------------------------------------------------ BASELINE configs[1]: full size, T = 4000
 @pytest.mark.parametrize("decode_v", ["3", "2"])
 def test_full_size_greedy_T4000_bit_exact(gold_full, manifest, monkeypatch, decode_v):
