@@ -1210,16 +1210,12 @@ extern "C" int er_prefill(er_ctx* c, const float* embeds, int B, int S, void* st
     ERCHK(ensure(c->p_f, (size_t)M * I));
     float *h = c->p_h.p, *q = c->p_q.p, *a = c->p_a.p, *y = c->p_y.p, *f = c->p_f.p;
     const int tail = prefill_tail_rows(c, M), Mm = M - tail;
-    // STAGED, off by default (ER_FLASH32_KSPLIT=1; not yet run on the GPU): the causal attention of a single prefix split over two
-    // key ranges per query tile (k_flash_attn_f32.h, KSP) - only where the launch has at most 768 two-wave workgroups, i.e. B = 1
+    // the causal attention of a single prefix is split over two key ranges per query tile (k_flash_attn_f32.h, KSP; same rule as the launcher)
     bool attn_ksplit = false;
-    if (!c->fast && D == 96) {
-        const char* v = getenv("ER_FLASH32_KSPLIT");
-        if (v && atoi(v) == 1 && (long long)((S + 63) / 64) * NH * B <= 768) {
-            ERCHK(ensure(c->p_ap, flash32_part_o_floats(B, NH, S, D)));
-            ERCHK(ensure(c->p_aml, flash32_part_ml_floats(B, NH, S)));
-            attn_ksplit = true;
-        }
+    if (!c->fast && flash32_ksplit(S, NH, B, D, true)) {
+        ERCHK(ensure(c->p_ap, flash32_part_o_floats(B, NH, S, D)));
+        ERCHK(ensure(c->p_aml, flash32_part_ml_floats(B, NH, S)));
+        attn_ksplit = true;
     }
 
     // hidden = inputs_embeds + pos_embeds(0..S)                       modeling_opt.py:355-357
@@ -1806,9 +1802,8 @@ extern "C" int er_k_flash_attn_f32(const float* q, const float* k, const float* 
     a.qs_b = (long long)N * H * D; a.os_b = a.qs_b; a.ks_b = (long long)M * H * D; a.vs_b = a.ks_b;
     a.qs_h = a.ks_h = a.vs_h = a.os_h = D;
     a.sqrt_d = sqrtf((float)D); a.causal_off = M - N;
-    const char* ksv = getenv("ER_FLASH32_KSPLIT");         // staged key-range split of the causal prefill shape (k_flash_attn_f32.h, KSP)
-    float *po = nullptr, *pml = nullptr;
-    if (ksv && atoi(ksv) == 1 && causal && D == 96) {
+    float *po = nullptr, *pml = nullptr;                   // key-range split of the causal prefill shape (k_flash_attn_f32.h, KSP)
+    if (flash32_ksplit(N, H, B, D, causal != 0)) {
         HIPCHK(hipMalloc(&po, flash32_part_o_floats(B, H, N, D) * 4));
         HIPCHK(hipMalloc(&pml, flash32_part_ml_floats(B, H, N) * 4));
         a.part_o = po; a.part_ml = pml;

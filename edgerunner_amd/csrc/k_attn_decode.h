@@ -68,6 +68,72 @@ __device__ __forceinline__ void kv_unpack(const f32x4& raw, float (&f)[KVec<KT>:
     }
 }
 
+// ---- fp16 cache: lanes mapped over PAIRS of key rows (round 5).
+//
+// A row of the fp16 cache is 96 halves = 192 bytes = one and a half 128-byte lines.  The first fp16 mapping gave a row to 4 lanes x
+// 3 loads, so load j of a wave read the j-th 64-byte THIRD of 16 rows: sixteen half-used lines per wave-instruction, every line
+// requested by two instructions - 12 % below the rate of whole-line requests at the same bytes (5.8 vs 5.15 us for 25 MB, 6.3 vs
+// 7.2 TB/s incremental: scripts/probes/attn_load_pattern_probe.hip, profiles/r05_attn_load_pattern_probe.log; the fp32 cache's
+// 384-byte rows already are whole lines and measure like a contiguous stream).  Two consecutive rows starting at an EVEN key are
+// 384 bytes = three whole lines, so 8 lanes x 3 loads take a pair (A, B): lane p of the group reads the p-th 16 bytes of line j.
+// In units of 8-half chunks ("parts" 0..11 of a row):
+//     load 0: row A part p          load 1: p < 4 ? row A part 8 + p : row B part p - 4          load 2: row B part 4 + p
+// Scores: a = t0 + (p < 4 ? t1 : 0), b = (p < 4 ? 0 : t1) + t2 summed over the 8 lanes; weights: pA on load 0, pA / pB on load 1,
+// pB on load 2.  Every part is accumulated by two (lane, load) slots 4 lanes apart; hpair_fold() adds them with row_ror:4.
+struct HPair {
+    int p; bool lo; int part1;
+    __device__ __forceinline__ explicit HPair(int lane) : p(lane & 7), lo((lane & 7) < 4), part1((lane & 7) < 4 ? 8 + (lane & 7) : (lane & 7) - 4) {}
+};
+
+__device__ __forceinline__ void hpair_load_q(const float* qp, const HPair& hp, float (&qv)[3][8]) {
+    const int part[3] = {hp.p, hp.part1, 4 + hp.p};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + part[j] * 8 + e);
+            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+        }
+}
+// rA / rB: the rows this lane reads for key A / key B of its pair (a masked key reads a valid row: its weight is 0)
+__device__ __forceinline__ void hpair_load(const _Float16* base, int rA, int rB, const HPair& hp, f32x4 (&r)[3]) {
+    r[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (long long)rA * 96 + hp.p * 8));
+    r[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (long long)(hp.lo ? rA : rB) * 96 + hp.part1 * 8));
+    r[2] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (long long)rB * 96 + (4 + hp.p) * 8));
+}
+__device__ __forceinline__ float hpair_dot8(const f32x4& raw, const float (&q)[8]) {
+    float f[8];
+    kv_unpack<_Float16>(raw, f);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(q[e], f[e], acc);
+    return acc;
+}
+__device__ __forceinline__ void hpair_scores(const f32x4 (&k)[3], const float (&qv)[3][8], const HPair& hp, float& sA, float& sB) {
+    const float t0 = hpair_dot8(k[0], qv[0]), t1 = hpair_dot8(k[1], qv[1]), t2 = hpair_dot8(k[2], qv[2]);
+    sA = lane_group_sum<8>(t0 + (hp.lo ? t1 : 0.f));
+    sB = lane_group_sum<8>((hp.lo ? 0.f : t1) + t2);
+}
+__device__ __forceinline__ void hpair_accum(const f32x4 (&v)[3], float pA, float pB, const HPair& hp, float (&o)[3][8]) {
+    const float w[3] = {pA, hp.lo ? pA : pB, pB};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float f[8];
+        kv_unpack<_Float16>(v[j], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[j][e] = fmaf(w[j], f[e], o[j][e]);
+    }
+}
+// o[j][e] already summed over the two lane groups of the row of 16 (o += row_ror<8>(o)): main = part p (all 8 lanes), hi = part 8 + p
+// (lanes p < 4 only)
+__device__ __forceinline__ void hpair_fold(const float (&o)[3][8], const HPair& hp, float (&main)[8], float (&hi)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        main[e] = o[0][e] + row_ror<4>(hp.lo ? o[2][e] : o[1][e]);     // a lane hands its receiver (4 lanes below) what THAT lane lacks
+        hi[e] = o[1][e] + row_ror<4>(o[2][e]);
+    }
+}
+
 // grid (S, H, B), 256 threads.  LPK lanes cover one key row with NV 16-byte loads each (full 128-byte
 // lines per wave-instruction); a wave step covers 64/LPK keys, the workgroup chunk is 4*STEPS*(64/LPK) keys:
 // wave w, step i, lane group g -> key k0 + KPS*i + KPW*w + g.
@@ -391,6 +457,9 @@ __global__ __launch_bounds__(ER_WG) void attn_combine2_kernel(AttnDecArgs a) {
 // Partials: o rows [B][H][NCH][D] (16-byte aligned float4 columns) and {m, l} pairs [B][H][NCH][2].
 constexpr int A3_LD = 97;     // row stride of the wave partials in LDS (D + 1: lanes that read a column down the rows hit 32 different banks)
 
+template <int D, int NW>
+__device__ __forceinline__ void attn3_merge_rows(float* ored, const float* wm, const float* wl, float* po, float* pml);
+
 template <typename KT, int D, int NS, int NW>
 __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, const KT* vb,
                                            const float (&qv)[D / (KVec<KT>::EPL * KVec<KT>::LPK)][KVec<KT>::EPL], int k0, int k1,
@@ -478,6 +547,13 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
     if (lane == 0) { wm[wid] = m; wl[wid] = l; }
     __syncthreads();
     ER_TP(5);
+    attn3_merge_rows<D, NW>(ored, wm, wl, po, pml);
+    ER_TP(7);
+}
+
+template <int D, int NW>
+__device__ __forceinline__ void attn3_merge_rows(float* ored, const float* wm, const float* wl, float* po, float* pml) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // ONE barrier: the 4 * NW = 64 row partials {wave k, row r of 16 lanes} of a column meet in the 64 lanes of ONE wave - wave w
     // owns columns [w * D/NW, (w + 1) * D/NW), lane = 4k + r reads them from row (k, r) (row stride A3_LD = D + 1 floats: conflict
     // free), weighs them with exp(m_k - M) and the wave adds them up: four row_ror steps inside each row of 16 lanes, then the four
@@ -516,6 +592,78 @@ __device__ __forceinline__ void attn3_body(const AttnDecArgs& a, const KT* kb, c
         po[wid * CPW + lane - 48] = v;
     }
     if (tid == 63) { pml[0] = M; pml[1] = acc[CPW]; }
+}
+// the fp16-cache body of the balanced kernel on the PAIR mapping above (k0 even: the chunk length of the fp16 kernel is rounded up to
+// an even number of keys); everything behind the row partials - the one-barrier merge of the 4 * NW rows - is shared with the fp32 body
+template <int D, int NS, int NW>
+__device__ __forceinline__ void attn3_body_h(const AttnDecArgs& a, const _Float16* kb, const _Float16* vb, const float (&qv)[3][8], int k0, int k1,
+                                             float* ored, float* wm, float* wl, float* po, float* pml) {
+    static_assert(D == 96, "pair mapping: 96 halves per row");
+    constexpr int KPW = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const HPair hp(lane);
+    const int g = lane >> 3;
+    f32x4 kreg[NS][3], vreg[NS][3];
+    bool vA[NS], vB[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int kA = k0 + (i * NW + wid) * KPW + 2 * g;
+        vA[i] = kA < k1;
+        vB[i] = kA + 1 < k1;
+        hpair_load(kb, vA[i] ? kA : k0, vB[i] ? kA + 1 : k0, hp, kreg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int kA = k0 + (i * NW + wid) * KPW + 2 * g;
+        hpair_load(vb, vA[i] ? kA : k0, vB[i] ? kA + 1 : k0, hp, vreg[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ER_TP(2);
+    float scA[NS], scB[NS];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        float sA, sB;
+        hpair_scores(kreg[i], qv, hp, sA, sB);
+        scA[i] = vA[i] ? sA / a.sqrt_d : -INFINITY;
+        scB[i] = vB[i] ? sB / a.sqrt_d : -INFINITY;
+        mloc = fmaxf(mloc, fmaxf(scA[i], scB[i]));
+    }
+    const float m = wave_max(mloc);           // -inf when the wave holds no valid key
+    ER_TP(3);
+    float o[3][8];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[j][e] = 0.f;
+    float lloc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const float pA = vA[i] ? expf(scA[i] - m) : 0.f, pB = vB[i] ? expf(scB[i] - m) : 0.f;
+        if (hp.p == 0) lloc += pA + pB;
+        hpair_accum(vreg[i], pA, pB, hp, o);
+    }
+    const float l = wave_sum(lloc);
+    ER_TP(4);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[j][e] += row_ror<8>(o[j][e]);
+    float om[8], oh[8];
+    hpair_fold(o, hp, om, oh);
+    if ((lane & 15) < 8) {
+        float* dst = ored + (wid * 4 + (lane >> 4)) * A3_LD;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[hp.p * 8 + e] = om[e];
+        if (hp.lo) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[(8 + hp.p) * 8 + e] = oh[e];
+        }
+    }
+    if (lane == 0) { wm[wid] = m; wl[wid] = l; }
+    __syncthreads();
+    ER_TP(5);
+    attn3_merge_rows<D, NW>(ored, wm, wl, po, pml);
     ER_TP(7);
 }
 
@@ -554,7 +702,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(const int* plen, 
     const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
     const float* qp = a.q + (long long)b * a.hidden + h * D;
     float qv[NV][EPL];
-    {
+    if constexpr (sizeof(KT) == 2) {
+        hpair_load_q(qp, HPair(threadIdx.x & 63), qv);          // pair mapping (fp16 cache): NV = 3 loads of EPL = 8 halves
+    } else {
         const int p = threadIdx.x & (LPK - 1);
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -565,7 +715,8 @@ __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(const int* plen, 
             }
     }
     const int len = a.fixed_len > 0 ? a.fixed_len : lmem + a.len_add;
-    const int clen = (len + nch - 1) >> __builtin_ctz(nch);      // <= STEPS * NW * KPW (the launcher checks l_cap and that nch is 16 / 32)
+    int clen = (len + nch - 1) >> __builtin_ctz(nch);            // <= STEPS * NW * KPW (the launcher checks l_cap and that nch is 16 / 32)
+    if constexpr (sizeof(KT) == 2) clen = (clen + 1) & ~1;       // fp16 cache: chunks start at even keys (a pair of rows = three whole lines)
     const int k0 = c * clen, k1 = min(len, k0 + clen);
     if (k0 >= k1) {                                        // empty chunk (len < nch): a partial the merge weighs with exp(-inf) = 0
         if (threadIdx.x < D) po[threadIdx.x] = 0.f;
@@ -574,6 +725,11 @@ __global__ __launch_bounds__(64 * NW) void attn_decode3_kernel(const int* plen, 
     }
     const int nsteps = (k1 - k0 + NW * KPW - 1) / (NW * KPW);      // workgroup-uniform
     ER_TP(1);
+    if constexpr (sizeof(KT) == 2) {
+        static_assert(sizeof(KT) != 2 || STEPS == 2, "fp16 cache: two wave-steps of 16 keys");
+        if (nsteps >= 2) attn3_body_h<D, 2, NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+        else attn3_body_h<D, 1, NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    } else
     if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
     else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
     else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
@@ -619,6 +775,21 @@ template <typename KT, int D, int STEPS>
 __device__ __forceinline__ void attn_stream_load(AttnTile<KT, D, STEPS>& t, const KT* kb, const KT* vb, int kbase, int len, int wid,
                                                  int g, int p) {
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK), KPW = 64 / LPK;
+    if constexpr (sizeof(KT) == 2) {              // fp16 cache: pair mapping (whole 128-byte lines), kbase is a multiple of the tile = even
+        const int lane = g * LPK + p;
+        const HPair hp(lane);
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kA = kbase + (i * ER_NWAVES + wid) * KPW + 2 * (lane >> 3);
+            hpair_load(kb, max(0, min(kA, len - 1)), max(0, min(kA + 1, len - 1)), hp, t.k[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kA = kbase + (i * ER_NWAVES + wid) * KPW + 2 * (lane >> 3);
+            hpair_load(vb, max(0, min(kA, len - 1)), max(0, min(kA + 1, len - 1)), hp, t.v[i]);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
         const int kk = max(0, min(kbase + (i * ER_NWAVES + wid) * KPW + g, len - 1));    // clamped: never reads the unused tail
@@ -640,6 +811,41 @@ __device__ __forceinline__ void attn_stream_reduce(const AttnTile<KT, D, STEPS>&
                                                    int kbase, int len, int wid, int g, int p, float sqrt_d, float& m_run, float& l_lane,
                                                    float (&o)[D / (KVec<KT>::EPL * KVec<KT>::LPK)][KVec<KT>::EPL]) {
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK), KPW = 64 / LPK;
+    if constexpr (sizeof(KT) == 2) {              // fp16 cache: pair mapping, two keys (A, B) per 8 lanes
+        const int lane = g * LPK + p;
+        const HPair hp(lane);
+        float scA[STEPS], scB[STEPS];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kA = kbase + (i * ER_NWAVES + wid) * KPW + 2 * (lane >> 3);
+            float sA, sB;
+            hpair_scores(t.k[i], qv, hp, sA, sB);
+            scA[i] = kA < len ? sA / sqrt_d : -INFINITY;
+            scB[i] = kA + 1 < len ? sB / sqrt_d : -INFINITY;
+            mloc = fmaxf(mloc, fmaxf(scA[i], scB[i]));
+        }
+        const float m_new = fmaxf(m_run, wave_max(mloc));
+        if (m_new == -INFINITY) return;
+        const float alpha = expf(m_run - m_new);
+        float pA[STEPS], pB[STEPS];
+        float ladd = 0.f;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            pA[i] = expf(scA[i] - m_new);
+            pB[i] = expf(scB[i] - m_new);
+            ladd += pA[i] + pB[i];
+        }
+        l_lane = fmaf(l_lane, alpha, hp.p == 0 ? ladd : 0.f);
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[j][e] *= alpha;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) hpair_accum(t.v[i], pA[i], pB[i], hp, o);
+        m_run = m_new;
+        return;
+    }
     float sc[STEPS];
     float mloc = -INFINITY;
 #pragma unroll
@@ -701,13 +907,17 @@ __global__ __launch_bounds__(ER_WG) void attn_stream_kernel(AttnDecArgs a) {
     const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
     float qv[NV][EPL];
     const float* qp = a.q + (long long)b * a.hidden + h * D;
+    if constexpr (sizeof(KT) == 2) {
+        hpair_load_q(qp, HPair(lane), qv);
+    } else {
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
+        for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int e = 0; e < EPL; e += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
-            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
-        }
+            for (int e = 0; e < EPL; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+                qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+            }
+    }
     float o[NV][EPL];
 #pragma unroll
     for (int j = 0; j < NV; ++j)
@@ -733,12 +943,22 @@ __global__ __launch_bounds__(ER_WG) void attn_stream_kernel(AttnDecArgs a) {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            o[j][e] += row_ror<8>(o[j][e]);
-            if (LPK == 4) o[j][e] += row_ror<4>(o[j][e]);
-        }
+        for (int e = 0; e < EPL; ++e) o[j][e] += row_ror<8>(o[j][e]);
     const float l = wave_sum(l_lane);
-    if ((lane & 15) < LPK) {
+    if constexpr (sizeof(KT) == 2) {          // pair mapping: every part sits in two (lane, load) slots 4 lanes apart
+        const HPair hp(lane);
+        float om[8], oh[8];
+        hpair_fold(o, hp, om, oh);
+        if ((lane & 15) < 8) {
+            float* dst = ored + (wid * 4 + (lane >> 4)) * D;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[hp.p * 8 + e] = om[e];
+            if (hp.lo) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[(8 + hp.p) * 8 + e] = oh[e];
+            }
+        }
+    } else if ((lane & 15) < LPK) {
         float* dst = ored + (wid * 4 + (lane >> 4)) * D;
 #pragma unroll
         for (int j = 0; j < NV; ++j)

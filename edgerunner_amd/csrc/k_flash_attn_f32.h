@@ -234,7 +234,8 @@ __global__ __launch_bounds__(ER_WG) void flash32_merge_kernel(Flash32Args a, int
         const float m1 = a.part_ml[2 * (half_rows + row)], l1 = a.part_ml[2 * (half_rows + row) + 1];
         const float m = fmaxf(m0, m1);
         const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - m), w1 = (m1 == -INFINITY) ? 0.f : expf(m1 - m);
-        const float den = l0 * w0 + l1 * w1;
+        float den = l0 * w0 + l1 * w1;
+        if (den == 0.f) den = 1.f;                     // a query with no visible key in either half (not a causal-prefill case): o = 0, not NaN
         const f32x4 o0 = *reinterpret_cast<const f32x4*>(a.part_o + row * D + 4 * c4);
         const f32x4 o1 = *reinterpret_cast<const f32x4*>(a.part_o + (half_rows + row) * D + 4 * c4);
         f32x4 o;
@@ -247,15 +248,25 @@ __global__ __launch_bounds__(ER_WG) void flash32_merge_kernel(Flash32Args a, int
 inline size_t flash32_part_o_floats(int B, int H, int N, int D) { return (size_t)2 * B * H * N * D; }
 inline size_t flash32_part_ml_floats(int B, int H, int N) { return (size_t)4 * B * H * N; }
 
-inline hipError_t launch_flash_attn_f32(const Flash32Args& a, int D, bool causal, int H, int B, hipStream_t st) {
-    // two-wave workgroups while four-wave ones would leave fewer than three per CU (ER_FLASH32_NWV = 2 / 4 forces one)
+// waves per workgroup of a launch: two while four-wave workgroups would leave fewer than three per CU (ER_FLASH32_NWV = 2 / 4 forces one)
+inline int flash32_waves(int N, int H, int B) {
     static const int forced = [] { const char* v = getenv("ER_FLASH32_NWV"); return v ? atoi(v) : 0; }();
-    const long long wg4 = (long long)((a.N + 4 * FA32_QW - 1) / (4 * FA32_QW)) * H * B;
-    const int nwv = (forced == 2 || forced == 4) ? forced : (wg4 < 768 ? 2 : 4);
+    const long long wg4 = (long long)((N + 4 * FA32_QW - 1) / (4 * FA32_QW)) * H * B;
+    return (forced == 2 || forced == 4) ? forced : (wg4 < 768 ? 2 : 4);
+}
+// Key-range split of the causal D = 96 launch (KSP): on wherever the launch runs two-wave workgroups, i.e. the single-prefix prefill
+// (encode + prefill 38.3 -> 37.9 ms, profiles/r05_ksplit.log); ER_FLASH32_KSPLIT=0 turns it off.  ONE rule for the callers that
+// allocate the partial buffers and for the launcher that uses them.
+inline bool flash32_ksplit(int N, int H, int B, int D, bool causal) {
+    const char* v = getenv("ER_FLASH32_KSPLIT");           // read per call (the tests compare both forms in one process)
+    return !(v && atoi(v) == 0) && causal && D == 96 && flash32_waves(N, H, B) == 2;
+}
+
+inline hipError_t launch_flash_attn_f32(const Flash32Args& a, int D, bool causal, int H, int B, hipStream_t st) {
+    const int nwv = flash32_waves(a.N, H, B);
     dim3 grid((a.N + nwv * FA32_QW - 1) / (nwv * FA32_QW), H, B), blk(64 * nwv);
-    // key-range split: only when the caller supplies the partial buffers (er_prefill / er_k_flash_attn_f32 under ER_FLASH32_KSPLIT=1 -
-    // staged, not yet measured on the GPU) and the launch is the single-sample causal prefill shape the split is for
-    if (a.part_o && a.part_ml && causal && D == 96 && nwv == 2 && (a.ldo & 3) == 0 && (a.os_b & 3) == 0 && (a.os_h & 3) == 0) {
+    // key-range split: when the caller supplies the partial buffers (it asks flash32_ksplit() too) and the output is float4-addressable
+    if (a.part_o && a.part_ml && flash32_ksplit(a.N, H, B, D, causal) && (a.ldo & 3) == 0 && (a.os_b & 3) == 0 && (a.os_h & 3) == 0) {
         grid.x *= 2;
         hipLaunchKernelGGL((flash_attn_f32_kernel<96, true, 2, true>), grid, blk, 0, st, a);
         hipError_t e = hipGetLastError();

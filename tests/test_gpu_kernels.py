@@ -447,23 +447,18 @@ def test_flash_attn_f32(B, H, N, M, D, causal):
     close(o, ref, 5e-6, 2e-5, "fp32 flash attention")
 
 
-# Staged code paths (written but not yet run on hardware; off by default in the product): their tests run only on request, so that
-# an unmeasured candidate can never turn the suite red - ER_TEST_CANDIDATES=1 python -m pytest tests -m gpu -k candidate
-candidate = pytest.mark.skipif(os.environ.get("ER_TEST_CANDIDATES") != "1", reason="staged candidate: set ER_TEST_CANDIDATES=1")
-
-
-@candidate
 @pytest.mark.parametrize("B,H,N,M", [(1, 16, 2050, 2050), (1, 2, 100, 100), (1, 2, 70, 200), (1, 1, 1, 1), (1, 3, 64, 64), (1, 2, 129, 129)])
-def test_candidate_flash_attn_f32_key_range_split(B, H, N, M, monkeypatch):
-    """ER_FLASH32_KSPLIT=1: the causal head_dim-96 prefill attention as two workgroups per query tile, each walking one half of its
-    key tiles, + flash32_merge_kernel (k_flash_attn_f32.h, KSP).  Same fp64 reference and tolerance as test_flash_attn_f32, and
-    within a few ulp of the unsplit kernel."""
+def test_flash_attn_f32_key_range_split(B, H, N, M, monkeypatch):
+    """The causal head_dim-96 prefill attention of a single prefix runs as two workgroups per query tile, each walking one half of
+    its key tiles, + flash32_merge_kernel (k_flash_attn_f32.h, KSP; default since round 5, ER_FLASH32_KSPLIT=0 = the unsplit
+    kernel).  Same fp64 reference and tolerance as test_flash_attn_f32, and within a few ulp of the unsplit kernel."""
     from edgerunner_amd import kernels as K_
     D = 96
     q, k, v = rnd(B, N, H * D, seed=83), rnd(B, M, H * D, seed=84), rnd(B, M, H * D, seed=85)
     k[:, M // 2] *= 3.0
+    monkeypatch.setenv("ER_FLASH32_KSPLIT", "0")
     base = K_.flash_attn_f32(q, k, v, H, causal=True)
-    monkeypatch.setenv("ER_FLASH32_KSPLIT", "1")
+    monkeypatch.delenv("ER_FLASH32_KSPLIT")
     o = K_.flash_attn_f32(q, k, v, H, causal=True)
     qh, kh, vh = (t.double().view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
     sc = qh @ kh.transpose(-1, -2) / math.sqrt(D)
@@ -473,6 +468,8 @@ def test_candidate_flash_attn_f32_key_range_split(B, H, N, M, monkeypatch):
     ref = (torch.softmax(sc, dim=-1) @ vh).transpose(1, 2).reshape(B, N, H * D)
     close(o, ref, 5e-6, 2e-5, "fp32 flash attention, key-range split")
     close(o, base.double(), 2e-6, 2e-6, "split vs unsplit kernel")
+    if N >= 2050:
+        assert not torch.equal(o, base), "the split did not engage"
 
 
 # ------------------------------------------------------------------ row ops

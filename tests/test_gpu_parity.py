@@ -887,14 +887,14 @@ def test_prefill_tail_rows_through_the_decode_gemv(gold_small, gold_full, monkey
     assert worst < LOGIT_TOL
 
 
-@pytest.mark.skipif(os.environ.get("ER_TEST_CANDIDATES") != "1", reason="staged candidate: set ER_TEST_CANDIDATES=1")
-def test_candidate_prefill_attention_key_range_split(gold_small, gold_full, monkeypatch):
-    """ER_FLASH32_KSPLIT=1 (staged, off by default): the single-sample exact prefill with its causal attention split over two key
-    ranges per query tile.  Golden ids bit for bit, logits within LOGIT_TOL, a few ulp from the unsplit prefill."""
+def test_prefill_attention_key_range_split(gold_small, gold_full, monkeypatch):
+    """The single-sample exact prefill runs its causal attention split over two key ranges per query tile (default since round 5;
+    ER_FLASH32_KSPLIT=0 = the unsplit kernel).  Golden ids bit for bit, logits within LOGIT_TOL, a few ulp from the unsplit prefill."""
     ids = gold_small["ids_min96"][0]
     lmm = make_lmm()
+    monkeypatch.setenv("ER_FLASH32_KSPLIT", "0")          # read per er_prefill call
     base = teacher_forced_logits(lmm, cloud(0), 1000, ids, {0, 1, 40})
-    monkeypatch.setenv("ER_FLASH32_KSPLIT", "1")          # read per er_prefill call
+    monkeypatch.delenv("ER_FLASH32_KSPLIT")
     _, toks = lmm.generate(cloud(0), 1000, tokenizer=object(), max_new_tokens=96, min_new_tokens=96)
     assert_ids(toks[0], ids, "prefill attention split over key ranges")
     got = teacher_forced_logits(lmm, cloud(0), 1000, ids, set(range(96)))
