@@ -336,6 +336,10 @@ def main(argv=None):
     B = args.batch_per_gpu
     opt = dataclasses.replace(config_defaults["ArAE"], num_layers=args.layers, generate_mode=args.mode)
 
+    if world > 1:
+        # N ranks generate the same synthetic weights on the host at once (2.7 GB of fp32 each): give every rank its share of the
+        # cores instead of N x all of them, so that the set-up of an 8-GPU run is not an oversubscribed host
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     t0 = time.time()
     lmm = LMM(opt, dev, precision=args.precision)
     esz = 4 if args.precision == "fp32" else 2

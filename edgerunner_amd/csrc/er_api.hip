@@ -623,8 +623,6 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     c->nch3 = attn3_num_chunks(H);
     HIPCHK(hipMalloc(&c->part, b * H * (size_t)std::max(S * (D + 2), c->nch3 * D) * 4));
     HIPCHK(hipMalloc(&c->part_ml, b * H * (size_t)c->nch3 * 2 * 4));
-    // split-K partials of the batched fc2: one [4][32][hidden] block per group of 32 rows (a deferred finish reads them a launch later)
-    HIPCHK(hipMalloc(&c->skpart, ((b + NBM - 1) / NBM) * (size_t)16 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     HIPCHK(hipMalloc(&c->state_block, (7 * b + 8) * sizeof(int)));
     int* sb = c->state_block;
     c->st.tok = sb; c->st.pos = sb + b; c->st.counter = sb + 2 * b; c->st.ngen = sb + 3 * b;
@@ -655,6 +653,10 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     // of K x 128 bytes per group of 32 rows; zeroed once so that the rows of a last, partial group never hold NaN patterns.
     const char* xe = getenv("ER_XT");
     c->xt = c->fast && c->batched && !c->batched_valu && !(xe && xe[0] == '0');
+    // split-K partials of the batched projections.  A finish launched right behind its producer re-uses ONE [4][32][N] block; only the
+    // tiled path defers finishes to a later launch (prep_rows_kernel, sk_part) and keeps a [16][32][hidden] block per group of 32 rows
+    HIPCHK(hipMalloc(&c->skpart, c->xt ? ((b + NBM - 1) / NBM) * (size_t)16 * NBM * (size_t)hid * 4
+                                       : (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
     if (c->xt) {
         const size_t groups = (size_t)(batch + NBM - 1) / NBM;
         const size_t b_h = groups * (size_t)hid * 128, b_f = groups * (size_t)g.intermediate_dim * 128;

@@ -20,6 +20,12 @@
 #pragma once
 #include "k_gemv.h"
 
+// timeline hooks of scripts/probes/gemv_mfma_timeline_probe.hip (expand to nothing in the library build)
+#ifndef ER_TPG
+#define ER_TPG(i)
+#define ER_TPG_WAIT(n)
+#endif
+
 namespace er {
 
 typedef float gm_f4 __attribute__((ext_vector_type(4)));
@@ -42,6 +48,7 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
     constexpr int XV = EPL / 4;
     __shared__ __attribute__((aligned(16))) float red[GM_WAVES][GM_R2 * NBH][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    ER_TPG(0);
     const int li = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * GM_ROWS;
     const int kbase = (blockIdx.y * GM_WAVES + wid) * GM_KW + kq * EPL;
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
     for (int c = 0; c < NLD; ++c)
 #pragma unroll
         for (int t = 0; t < GM_R2; ++t) w[t][c] = __builtin_nontemporal_load(wp[t] + c * 64);
+    // (weights issued in front of X measured equal at B = 16 / 32: profiles/r05_ab_gm_wfirst.log)
     // the output this thread finishes: slot = tid >> 8 = (row tile t, batch half h), lane image ol, register orr
     //   n = n0 + 16*t + 4*(ol >> 4) + orr,  b = 16*h + (ol & 15)
     const int slot = tid >> 8, ol = (tid >> 2) & 63, orr = tid & 3;
@@ -90,6 +98,11 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
     // keep every load above the first MFMA: without this the scheduler sinks the loads next to their uses to save
     // registers, and a wave then has a few hundred bytes in flight instead of its whole slice
     __builtin_amdgcn_sched_barrier(0);
+    ER_TPG(1);                          // every load issued
+    ER_TPG_WAIT(GM_R2 * NLD);           // probe only: the input image has landed (the weight loads are the youngest GM_R2 * NLD)
+    ER_TPG(2);
+    ER_TPG_WAIT(0);                     // probe only: the weights have landed
+    ER_TPG(3);
     gm_f4 acc[GM_R2][NBH];
 #pragma unroll
     for (int t = 0; t < GM_R2; ++t)
@@ -163,7 +176,9 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
     for (int t = 0; t < GM_R2; ++t)
 #pragma unroll
         for (int h = 0; h < NBH; ++h) *reinterpret_cast<gm_f4*>(&red[wid][t * NBH + h][lane][0]) = acc[t][h];
+    ER_TPG(4);                          // MFMAs done, partial tile in LDS
     __syncthreads();
+    ER_TPG(5);
     if constexpr (NWV != 16) {
         // 256 threads finish the GM_R2 * NBH output tiles one after the other (raw partials only)
 #pragma unroll
@@ -175,6 +190,7 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
             for (int wv = 0; wv < NWV; ++wv) s += red[wv][sl][ol][orr];
             if (n2 < a.N && b2 < nb_valid) part[((long long)blockIdx.y * nb_valid + b2) * a.N + n2] = s;
         }
+        ER_TPG(6);
         return;
     }
     if (slot < GM_R2 * NBH) {
@@ -193,6 +209,7 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
             else gemv_epilogue<EPI>(a, on, ob, s, pre);
         }
     }
+    ER_TPG(6);
 }
 
 // row-major [N][K] -> the tiled layout above; N is padded to a multiple of 16 with zero rows

@@ -57,10 +57,13 @@ __global__ __launch_bounds__(OM_THREADS) void outproj_merge_kernel(const void* p
     const int c4 = min(li, C4 - 1);           // lanes 24..31 of a half re-read column 23 (never stored)
     const f32x4* pcol = reinterpret_cast<const f32x4*>(a.part_o + (long long)head * NCH * D) + c4;
     f32x4 pv[NCH];
-#pragma unroll
-    for (int s = 0; s < NCH; ++s) pv[s] = pcol[s * C4];
     f32x4 w[J];
     const f32x4* wr = reinterpret_cast<const f32x4*>(reinterpret_cast<const WT*>(a.W) + (long long)row * K);
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) pv[s] = pcol[s * C4];
+    // (the weight row issued FIRST - its HBM round trip started before the address unit has worked through the 8 x 17 partial loads -
+    // measured slower, 4.80 vs 4.55 us fp32 and 4.17 vs 4.07 us fp16: the merge arithmetic then waits for it, loads return in order;
+    // profiles/r05_ab_om_wfirst.log)
 #pragma unroll
     for (int j = 0; j < J; ++j) w[j] = __builtin_nontemporal_load(wr + j * 64 + lane);
     __builtin_amdgcn_sched_barrier(0);

@@ -35,6 +35,16 @@ def test_bench_spawns_its_ranks_dry_run(gpus, batch):
         assert f"launching {gpus} ranks" in err
 
 
+def test_bench_eight_ranks_config3_dry_run():
+    """The driver's 8-GPU line (`bench.py --gpus 8 --config 3`): 8 ranks start, every one reports, the shard is configs[3]'s (VERDICT r4
+    item 7).  No GPU work: the fabricated streams travel through the same shard / gather / barrier / max-over-ranks code."""
+    out, err = run_bench("--gpus", 8, "--dry-run", "--config", 3, "--steps", 1, "--warmup", 1)
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and out["world_size_seen"] == 8
+    assert out["per_rank"]["ranks_reporting"] == 8
+    assert out["config"]["batch_per_gpu"] == 32 and out["scaling"] == "weak"
+    assert out["value"] > 0 and "launching 8 ranks" in err
+
+
 def test_bench_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

@@ -144,5 +144,6 @@ def test_prefill_tail_gemvs_are_in_the_code_object(kernels):
     for ks, rw, epi in ((1, 1, 2), (1, 2, 1), (4, 2, 2)):
         for nb in (1, 2, 3, 4):
             sel = select(kernels, rf"gemv_kernelIfLi{ks}ELi{nb}ELi{rw}ELi0ELi{epi}ELi4EEE")
+            assert sel, (ks, nb, rw, epi)       # (select() asserts too: an instantiation that is gone must not pass vacuously)
             for n, b in sel.items():
                 assert not [l for l in b if l.startswith("scratch_")], (n, "scratch access")
