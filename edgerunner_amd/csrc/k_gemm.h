@@ -511,6 +511,7 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
             for (int r = 0; r < 16; ++r) sw[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh) * WC + 32 * j + li] = acc[i][j][r];
     // (same wave writes and reads: the LDS queue is in order, no barrier)
     if constexpr (HEPI == HEPI_PLAIN) {
+        if (nw >= g.N) return;                // a wave whose whole column block lies beyond N (256-wide tiles on N % 256 != 0)
         if (g.vt16 && nw >= g.vt_col0) {      // wave-uniform: the V columns of this wave's block go out as V^T rows
             // lane -> (column d of the block, a run of WR / LPD keys): 16 keys per step = two 16-byte chunks of the V^T row in
             // fa_vt_pos order ({0-3, 8-11}, {4-7, 12-15}); the column walk down the LDS rows is conflict-free up to the two lanes
@@ -704,6 +705,111 @@ __global__ __launch_bounds__(ER_WG) void gemm_hh_mfma_kernel(GemmArgs g, int ntx
     gemm_hh_epilogue<TM, TN, HEPI>(g, sw, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same product on a 256 x 256 workgroup tile: 8 waves (2 x 4), each owning a 128 x 64 block = a 4 x 2 grid of 32 x 32 MFMA
+// accumulators (128 registers).  Round 4 measured why the 4-wave kernel above stops at ~850 TFLOP/s: a 64 x 64
+// block per wave reads 16 KB of fragments out of LDS per 64-deep k-step for 16 MFMAs, and deeper stages only trade occupancy away;
+// a 128 x 64 block reads 24 KB for 32 MFMAs - a third fewer LDS bytes per flop - and a 256 x 256 tile brings half the operand
+// bytes per flop through LDS-DMA (cdna_hip_programming.md section 5: the 256^2 tile with two LDS buffers at BK = 64).
+// Same 128-byte row images, same XOR swizzle, same fragment reads and the SAME MFMA sequence per accumulator element (k ascending
+// in steps of 16) as gemm_hh_mfma_kernel: bit-identical results.  Two stages of 64 KB = 128 KB of LDS, one workgroup per CU; the
+// epilogue runs the 64 x 64 row-wise epilogue of the 4-wave kernel twice per wave (rows 0..63, 64..127 of its block) through
+// its 16 KB slice of the idle stage buffers.  For the wide products only (launch_gemm_hh / launch_gemm_hh_geglu pick it when it
+// fills the chip: N = 8192 feed-forward-in and N = 3072 qkv of the DiT front-end).
+// LDS-DMA pieces issued from inline asm (hipcc treats the builtin as an LDS write every later ds_read may alias and parks a
+// vmcnt(0) in front of the fragment reads / inside __syncthreads; an asm statement is invisible to that bookkeeping, so the waits are
+// the counted ones written in the loop - same helper as k_flash_attn.h fa_glds16).  M0 (the LDS base) is saved and restored.
+__device__ __forceinline__ void gm_glds16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+constexpr int X256_BM = 256, X256_BN = 256, X256_THREADS = 512;
+template <int HEPI = HEPI_PLAIN>
+__global__ __launch_bounds__(X256_THREADS) void gemm_hh256_kernel(GemmArgs g, int ntx) {
+    constexpr int STAGE = (X256_BM + X256_BN) * XBK;                              // halves per stage: 256 A rows, then 256 B rows
+    constexpr int NPI = X256_BM / 8 / 8;                                          // 8-row LDS-DMA pieces per wave and operand (4)
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * STAGE];              // 128 KB: the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + within;
+    const int ty = lin / ntx, tx = lin - ty * ntx;
+    const int m0 = ty * X256_BM, n0 = tx * X256_BN;
+    const _Float16* A = reinterpret_cast<const _Float16*>(g.A);
+    const _Float16* B = reinterpret_cast<const _Float16*>(g.B);
+    const int nk = g.K / XBK;
+
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const _Float16* pa[NPI];
+    const _Float16* pb[NPI];
+#pragma unroll
+    for (int j = 0; j < NPI; ++j) {
+        const int r = 8 * (wid * NPI + j) + lrow;
+        pa[j] = A + (long long)min(m0 + r, g.M - 1) * g.lda + ((lslot ^ ((r >> 1) & 7)) << 3);
+        pb[j] = B + (long long)min(n0 + r, g.N - 1) * g.ldb + ((lslot ^ ((r >> 1) & 7)) << 3);
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(er_lptr)lds;              // LDS byte address of the array
+    auto issue = [&](int kt, int s) {
+        const unsigned as = lds0 + (unsigned)(s * STAGE) * 2u, bs = as + X256_BM * XBK * 2u;
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) gm_glds16(pa[j] + kt * XBK, as + 8u * (wid * NPI + j) * XBK * 2u);
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) gm_glds16(pb[j] + kt * XBK, bs + 8u * (wid * NPI + j) * XBK * 2u);
+    };
+    // (an L2 prefetch of the k-tile two steps ahead - one 4-byte LDS-DMA per lane and line into a dump area, left out of the counted
+    // wait - measured SLOWER: 942 vs 990 TFLOP/s at 4096^3, 910 vs 1045 at 8192^3; profiles/r05_gemm_hh256_probe_with_l2_prefetch.log)
+    constexpr int TM = 4, TN = 2;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kh = lane >> 5, li = lane & 31, swz = (li >> 1) & 7;
+    if (nk > 0) issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        const _Float16* as = lds + cur * STAGE + (wm * 32 * TM + li) * XBK;
+        const _Float16* bs = lds + cur * STAGE + X256_BM * XBK + (wn * 32 * TN + li) * XBK;
+        // fragments double-buffered in registers: the six reads of k-step ks + 1 are in flight under the eight MFMAs of k-step ks
+        // (left to itself hipcc re-used one register set and put an lgkmcnt(0) in front of every group of four MFMAs)
+        h16x8 av[2][TM], bv[2][TN];
+        auto frags = [&](int ks, int buf) {
+            const int co = ((2 * ks + kh) ^ swz) << 3;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[buf][j] = *reinterpret_cast<const h16x8*>(bs + 32 * j * XBK + co);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[buf][i] = *reinterpret_cast<const h16x8*>(as + 32 * i * XBK + co);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < XBK / 16; ++ks) {
+            if (ks + 1 < XBK / 16) frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // this wave's pieces of the next tile have landed, every fragment read of `cur` has returned (its MFMAs are issued) - then
+        // the barrier: everybody's pieces are in, everybody is done reading `cur`
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // every wave is past the last barrier: the stage buffers are free; wave w's 64 x 64 floats (16 KB) fit its eighth of them
+    static_assert(8 * 64 * 64 * 4 <= 2 * STAGE * 2, "epilogue staging fits the stage buffers");
+    float* sw = reinterpret_cast<float*>(lds) + wid * (64 * 64);
+    const int mw = m0 + wm * 32 * TM, nw = n0 + wn * 32 * TN;
+    gemm_hh_epilogue<2, 2, HEPI>(g, sw, *reinterpret_cast<const f32x16(*)[2][TN]>(&acc[0]), mw, nw, lane);
+    gemm_hh_epilogue<2, 2, HEPI>(g, sw, *reinterpret_cast<const f32x16(*)[2][TN]>(&acc[2]), mw + 64, nw, lane);
+}
+
 // fp32 -> fp16 copy of a row-major matrix (the A operand of gemm_hh_mfma_kernel when no producer wrote one)
 __global__ __launch_bounds__(ER_WG) void cvt_rows_f16_kernel(const float* x, _Float16* y, long long rows, int cols, int ldx, int ldy) {
     const long long total = rows * cols;
@@ -854,8 +960,17 @@ inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT o
 // tile choice of the LDS-DMA kernel (see gemm_pick_tile): placeholder rule, tuned by scripts/probes/gemm_hh_probe.hip
 // (profiles/r03_gemm_hh_probe.log): 128x128 wants two workgroups per CU (its 64 KB of stages allow no more); below that 64x128
 // at >= 1 per CU beats both 128x128 at < 2 per CU and 64x64 (4096 x 1024 x 4096: 51 vs 54 vs 62 us)
+// 256 x 256 (8 waves, one workgroup per CU) when its tiles fill the chip (one workgroup per CU and more; at 192 tiles - the DiT's
+// qkv product - it measured slower than 128 x 128: 47.6 vs 41.5 us, profiles/r05_gemm_hh256_probe.log):
+// ER_GEMM256=0 restores the round-4 rule
+inline bool gemm_hh_use_256(int M, int N) {
+    static const bool off = [] { const char* v = getenv("ER_GEMM256"); return v && atoi(v) == 0; }();
+    const long long t = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    return !off && t >= 256;
+}
 inline int gemm_hh_pick_tile(int M, int N) {
     auto wgs = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (gemm_hh_use_256(M, N)) return 4;
     if (wgs(128, 128) >= 512) return 1;
     if (wgs(64, 128) >= 256) return 2;
     return 3;
@@ -868,6 +983,12 @@ inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st, int force_ti
                    g.gate || g.resid))
         return hipErrorInvalidValue;
     const int tile = force_tile ? force_tile : gemm_hh_pick_tile(g.M, g.N);
+    if (tile == 4) {          // 256 x 256, 8 waves (the V^T epilogue walks 64-row runs: fine, 64 | 256)
+        const int ntx4 = (g.N + X256_BN - 1) / X256_BN;
+        const dim3 grid4(ntx4 * ((g.M + X256_BM - 1) / X256_BM));
+        hipLaunchKernelGGL((gemm_hh256_kernel<HEPI_PLAIN>), grid4, dim3(X256_THREADS), 0, st, g, ntx4);
+        return hipGetLastError();
+    }
     const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
     const int ntx = (g.N + bn - 1) / bn, nty = (g.M + bm - 1) / bm;
     const dim3 grid(ntx * nty);
@@ -921,6 +1042,12 @@ __global__ __launch_bounds__(ER_WG) void geglu_permute_kernel(const _Float16* w,
 // g.N = 2F (a multiple of 128), g.c16 = out16; no fp32 output
 inline hipError_t launch_gemm_hh_geglu(const GemmArgs& g, hipStream_t st) {
     if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7) || (g.N & 127) || !g.c16 || !g.bias) return hipErrorInvalidValue;
+    if ((g.N & 255) == 0 && gemm_hh_use_256(g.M, g.N)) {
+        const int ntx4 = g.N / 256;
+        const dim3 grid4(ntx4 * ((g.M + 255) / 256));
+        hipLaunchKernelGGL((gemm_hh256_kernel<HEPI_GEGLU>), grid4, dim3(X256_THREADS), 0, st, g, ntx4);
+        return hipGetLastError();
+    }
     const int ntx = g.N / 128;
     if ((long long)((g.M + 127) / 128) * ntx >= 768) {
         hipLaunchKernelGGL((gemm_hh_mfma_kernel<2, 2, HEPI_GEGLU>), dim3(ntx * ((g.M + 127) / 128)), dim3(ER_WG), 0, st, g, ntx);

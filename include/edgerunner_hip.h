@@ -283,7 +283,7 @@ int er_k_gemm_hh(const float* a_dev, const void* w_half_dev, const float* bias_d
  * columns are left untouched), the V third written by the GEMM epilogue as V^T per head into vt_out_dev
  * [m / rows_per_batch][heads][64][rows_per_batch], keys in the order flash_attn_hh_kernel reads them (position of key k inside its
  * group of 16: {0-3, 8-11, 4-7, 12-15}).  m, rows_per_batch multiples of 64; force_tile 0 = the product rule, 1 / 2 / 3 = 128x128 /
- * 64x128 / 64x64 tiles. */
+ * 64x128 / 64x64 tiles (4 waves), 4 = 256x256 (8 waves). */
 int er_k_gemm_hh_qkv(const float* a_dev, const void* w_half_dev, const float* bias_dev, void* qk16_out_dev, void* vt_out_dev, int m,
                      int n, int k, int rows_per_batch, int force_tile, void* stream);
 int er_k_gemm_f16s(const float* a, const void* w_half, const float* bias, const float* resid, float* c, int m, int n, int k,

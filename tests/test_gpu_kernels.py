@@ -326,11 +326,12 @@ def test_gemm_f16_input_mfma(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (4096, 3072, 1024), (4096, 1024, 4096), (4096, 64, 1024), (514, 1024, 1024),
-                                   (77, 200, 640), (300, 8192, 1024), (129, 65, 128)])
+                                   (77, 200, 640), (300, 8192, 1024), (129, 65, 128), (3001, 4164, 192), (4096, 8192, 128)])
 def test_gemm_hh_lds_dma(M, N, K):
     """fp16 x fp16 GEMM with both operands brought in by LDS-DMA into an XOR-swizzled image (DiT Linears in fp16 mode): must be
     BIT-IDENTICAL to the register-staged fp16 kernel (same fp16-rounded operands, same k order per MFMA, same epilogue), for all
-    three tile shapes, ragged edges and the XCD-aware tile order; the fp16 copy of the output is the rounded fp32 output."""
+    tile shapes - the three 4-wave ones and the 8-wave 256 x 256 tile the rule picks from 192 tiles up (4096 x 3072, the ragged
+    3001 x 4164, 4096 x 8192) -, ragged edges and the XCD-aware tile order; the fp16 copy of the output is the rounded fp32 output."""
     from edgerunner_amd import kernels as K_
     a, w = rnd(M, K, seed=84), rnd(N, K, seed=85, scale=0.05)
     bias, resid = rnd(N, seed=86), rnd(M, N, seed=87)
@@ -349,7 +350,7 @@ def test_gemm_hh_lds_dma(M, N, K):
         assert torch.equal(K_.gemm_hh(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,rows,heads,K", [(4096, 2048, 16, 1024), (256, 64, 2, 64), (384, 128, 4, 192)])
 def test_gemm_hh_qkv_writes_v_transposed(M, rows, heads, K, tile):
     """The q/k/v projection of the DiT self-attention (core/transformer/dit.py:100-126): q and k leave the GEMM as fp16 rows, V as
