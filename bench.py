@@ -312,6 +312,37 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def attention_fit(samples, esz):
+    """Least-squares t = intercept + bytes / rate over the context sweep of the decode attention (bytes = 2 L 1536 esz per launch)."""
+    x = np.array([2.0 * s_["context_len"] * 1536 * esz for s_ in samples])
+    y = np.array([s_["attn_decode_us"] for s_ in samples])
+    if len(x) < 2 or float(np.ptp(x)) == 0.0:
+        return None
+    slope, icpt = np.polyfit(x, y, 1)
+    return {"intercept_us": round(float(icpt), 3), "slope_TBps": round(1.0 / float(slope) / 1e6, 3) if slope > 0 else None,
+            "form": "attn_decode_us = intercept_us + bytes / slope"}
+
+
+def decode_kernel_sweep(dec, L0, T, NS, repeats_mean=6):
+    """Per-kind launch times at the run's mean context + the attention kinds as a run average over NS contexts (see main)."""
+    mean_L = L0 + (T - 1) / 2.0 + 1.0
+    L_ref = int(round(mean_L))
+    prof = dec.profile_decode_kernels(repeats=repeats_mean, context_len=L_ref, use_graph=True)
+    samples = []
+    for i in range(NS):
+        L = L0 + 1 + int(round((i + 0.5) * T / NS)) if NS > 1 else L_ref
+        p = dec.profile_decode_kernels(repeats=3, context_len=L, use_graph=True)
+        samples.append({"context_len": L, "attn_decode_us": round(p["attn_decode"]["avg_us"], 3),
+                        "attn_combine_us": round(p["attn_combine"]["avg_us"], 3)})
+    at_mean = {k: prof[k]["avg_us"] for k in ("attn_decode", "attn_combine")}
+    for k in ("attn_decode", "attn_combine"):      # run average replaces the single point at the mean length
+        prof[k]["avg_us"] = float(np.mean([s_[k + "_us"] for s_ in samples]))
+    ends = {"at_mean_context": {"context_len": L_ref, "attn_decode_us": round(at_mean["attn_decode"], 3),
+                                "attn_combine_us": round(at_mean["attn_combine"], 3)},
+            "samples": samples}
+    return prof, ends, L_ref, mean_L
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -415,22 +446,9 @@ def main(argv=None):
     # algorithmic bytes of one launch at the MEAN context length / that mean duration.
     # scripts/roofline_from_rocprof.py recomputes `frac` from profiles/*_kernel_stats.csv and checks the two agree.
     L0 = PREFIX + args.resume_len
-    mean_L = L0 + (T - 1) / 2.0 + 1.0             # keys visible to the step (incl. the token being fed), run average
-    L_ref = int(round(mean_L))
-    prof = lmm.mesh_decoder.profile_decode_kernels(repeats=6, context_len=L_ref, use_graph=True)
     NS = 16 if T >= 64 else 1
-    samples = []
-    for i in range(NS):
-        L = L0 + 1 + int(round((i + 0.5) * T / NS)) if NS > 1 else L_ref
-        p = lmm.mesh_decoder.profile_decode_kernels(repeats=3, context_len=L, use_graph=True)
-        samples.append({"context_len": L, "attn_decode_us": round(p["attn_decode"]["avg_us"], 3),
-                        "attn_combine_us": round(p["attn_combine"]["avg_us"], 3)})
-    at_mean = {k: prof[k]["avg_us"] for k in ("attn_decode", "attn_combine")}
-    for k in ("attn_decode", "attn_combine"):      # run average replaces the single point at the mean length
-        prof[k]["avg_us"] = float(np.mean([s_[k + "_us"] for s_ in samples]))
-    ends = {"at_mean_context": {"context_len": L_ref, "attn_decode_us": round(at_mean["attn_decode"], 3),
-                                "attn_combine_us": round(at_mean["attn_combine"], 3)},
-            "samples": samples}
+    prof, ends, L_ref, mean_L = decode_kernel_sweep(lmm.mesh_decoder, L0, T, NS)
+    ends["fit"] = attention_fit(ends["samples"], esz)
     log("kernel sweep done")
     per_token_us = {k: v["avg_us"] * LAUNCHES_PER_TOKEN[k] for k, v in prof.items()}
     dom = max(per_token_us, key=per_token_us.get)
@@ -447,7 +465,7 @@ def main(argv=None):
         "context_len_at_measurement": L_ref,
         "note": f"run-average: mean launch duration over {NS} contexts spread over the timed run (contexts {L0 + 1}..{L0 + T}) and "
                 "the algorithmic bytes of one launch at the mean context length; reproduce with scripts/roofline_from_rocprof.py "
-                "on profiles/r04_*_kernel_stats.csv",
+                "on profiles/r05_*_kernel_stats.csv",
         "context_sweep": ends,
         "per_layer_kernel_sum_us": round(layer_us, 2),
         "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1) if v["avg_us"] > 0 else 0.0,
@@ -491,6 +509,19 @@ def main(argv=None):
                                  "hbm_frac": round(ftok * fb / 1e9 / HBM_PEAK_GBS, 4),
                                  "note": "fp16 weights + fp16 KV, fp32 accumulate; parity = ids exact / logits 5e-6 vs the "
                                          "oracle on fp16-rounded storage (tests/test_gpu_parity.py), ~1e-3 vs fp32"}
+        try:        # the fast mode's own per-kind table and context sweep: same method as `roofline` above
+            fprof, fends, fL, _ = decode_kernel_sweep(fast.mesh_decoder, L0, T, NS)
+            fends["fit"] = attention_fit(fends["samples"], 2)
+            fnames = kernel_names("fp16", False)
+            out["fast_mode_fp16"].update({
+                "context_len_at_measurement": fL, "context_sweep": fends,
+                "per_layer_kernel_sum_us": round(sum(fprof[k]["avg_us"] for k in ("qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv",
+                                                                                  "fc1_gemv", "fc2_gemv")), 2),
+                "kernels": {k: {"avg_us": round(v["avg_us"], 3), "kernel_name": (fnames.get(k) or ["?"])[0],
+                                "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1) if v["avg_us"] > 0 else 0.0,
+                                "us_per_token": round(v["avg_us"] * LAUNCHES_PER_TOKEN[k], 2)} for k, v in fprof.items()}})
+        except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the bench line
+            out["fast_mode_fp16"]["kernels_error"] = repr(e)[:200]
         # and the batched shard of BASELINE configs[3] (32 independent clouds per GPU), short run: aggregate decode rate
         try:
             Bx, Tx = 32, 256

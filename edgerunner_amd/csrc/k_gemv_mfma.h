@@ -114,10 +114,12 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
         // activations keep fp32 grade by entering as two fp16 numbers x = hi + lo (|x - hi - lo| <= 2^-22 |x|), one MFMA
         // each.  A lane's 8 weights of a piece split into two k-groups of 4 (elements 0-3 / 4-7 of every lane): the matrix
         // core sums k in any order, A and B only have to agree on which k sits in which (lane, element) slot.
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        // (round 5: ONE v_mfma_f32_16x16x32_f16 per piece instead of two 16x16x16 - gfx950's K = 32 form takes a lane's eight weights and
+        // eight inputs at once at the same issue cost, so the matrix phase of a B = 32 projection halves: 1.6 -> 0.8 us of the
+        // 7 us launch, profiles/r05_gemv_mfma_timeline.log)
 #pragma unroll
         for (int c = 0; c < NLD; ++c) {
-            h4 xh[NBH][2], xl[NBH][2];
+            f16x8 xh[NBH], xl[NBH];
 #pragma unroll
             for (int h = 0; h < NBH; ++h)
 #pragma unroll
@@ -125,28 +127,24 @@ __global__ __launch_bounds__(64 * NWV) void gemv_mfma_kernel(GemvArgs a, int nb_
                     if constexpr (XT) {        // the producer split the value: halves 0..3 = hi, 4..7 = lo of this k-quad
                         const f16x8 t = __builtin_bit_cast(f16x8, x[h][c][j]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { xh[h][j][e] = t[e]; xl[h][j][e] = t[4 + e]; }
+                        for (int e = 0; e < 4; ++e) { xh[h][4 * j + e] = t[e]; xl[h][4 * j + e] = t[4 + e]; }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float xv = x[h][c][j][e];
                             const _Float16 hi = (_Float16)xv;
-                            xh[h][j][e] = hi;
-                            xl[h][j][e] = (_Float16)(xv - (float)hi);
+                            xh[h][4 * j + e] = hi;
+                            xl[h][4 * j + e] = (_Float16)(xv - (float)hi);
                         }
                     }
                 }
 #pragma unroll
             for (int t = 0; t < GM_R2; ++t) {
-                const f16x8 hv = __builtin_bit_cast(f16x8, w[t][c]);
+                const f16x8 av = __builtin_bit_cast(f16x8, w[t][c]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const h4 av = {hv[4 * j], hv[4 * j + 1], hv[4 * j + 2], hv[4 * j + 3]};
-#pragma unroll
-                    for (int h = 0; h < NBH; ++h) {
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, xl[h][j], acc[t][h], 0, 0, 0);
-                        acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, xh[h][j], acc[t][h], 0, 0, 0);
-                    }
+                for (int h = 0; h < NBH; ++h) {
+                    acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, xl[h], acc[t][h], 0, 0, 0);
+                    acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, xh[h], acc[t][h], 0, 0, 0);
                 }
             }
         }

@@ -21,6 +21,8 @@ for SEC in "$@"; do
     gemm)    { timeout 300 scripts/probes/gemm_hh_probe 2>&1; timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider --timeout 400 -x -k "gemm_hh" 2>&1 | filt | tail -5; } | tee gpurun_out/r05_gemm_hh256_probe.log ;;
     dit)     { timeout 900 python -m pytest tests/test_gpu_dit.py -q -m gpu -s -p no:cacheprovider --timeout 600 2>&1 | filt | tail -12
                for G in 0 1 0 1; do echo "ER_GEMM256=$G"; ER_GEMM256=$G timeout 300 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_dit.log ;;
+    abx32)   { for L in edgerunner_amd/lib_prev.so edgerunner_amd/libedgerunner_hip.so edgerunner_amd/lib_prev.so edgerunner_amd/libedgerunner_hip.so; do echo "== $L"; ER_LIB_PATH=$ROOT/$L timeout 300 python scripts/bench_batch.py 16,32 600 1000 fp16 2>&1 | filt | grep -E "aggregate|per-kind" | cut -c1-260; done; } | tee gpurun_out/r05_ab_mfma_k32.log ;;
+    btests)  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider --timeout 600 -x -k "batch or fast_mode or fp16 or mfma or tiled or xt" 2>&1 | filt | tail -8 | tee gpurun_out/r05_batch_tests.log ;;
     ksplit)  { ER_TEST_CANDIDATES=1 timeout 600 python -m pytest tests -q -m gpu -k candidate -p no:cacheprovider --timeout 400 2>&1 | filt | tail -6
                for K in 0 1 0 1; do echo "ER_FLASH32_KSPLIT=$K"; ER_FLASH32_KSPLIT=$K timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ksplit.log ;;
   esac
