@@ -45,7 +45,11 @@ PREFIX = 2050                  # 2049 condition tokens + BOS
 LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "out_proj_gemv": 24, "fc1_gemv": 24,
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
 # committed rocprofv3 PMC summaries (scripts/gpu_round4.sh pmc / pmc3): single-row decode kernels, batched (B = 32) decode kernels
-PMC_SUMMARY = {False: os.path.join("profiles", "r04_pmc_hbm_summary.json"), True: os.path.join("profiles", "r04_pmc_hbm_config3_summary.json")}
+# committed PMC summaries, newest round first (a file that is not there yet falls through to the previous round's)
+PMC_SUMMARY = {("fp32", False): ["r05_pmc_hbm_summary.json", "r04_pmc_hbm_summary.json"],
+               ("fp16", False): ["r05_pmc_hbm_fp16_summary.json"],
+               ("fp16", True): ["r05_pmc_hbm_config3_summary.json", "r04_pmc_hbm_config3_summary.json"],
+               ("fp32", True): []}
 # the single-GPU configurations of BASELINE.json (configs[0] is the CPU path = cpu_baseline; configs[4] = dit_front_end_fp16)
 CONFIGS = {
     1: {"name": "BASELINE configs[1]", "batch": 1, "num_face": 1000, "mode": "greedy", "precision": "fp32"},
@@ -106,14 +110,14 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def pmc_traffic(kind, kernel_names, at_len, batched=False):
-    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes (profiles/r04_pmc_hbm_*summary.json:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes; separate --pmc runs, scripts/gpu_round4.sh pmc / pmc3).  Counters
-    cannot be read inside the timed process.  The attention passes run at a recorded context length (the PMC run starts its
-    decode at --resume-len); its bytes are scaled linearly to `at_len` keys, the length `bytes_per_launch` is quoted at."""
-    path = os.path.join(ROOT, PMC_SUMMARY[bool(batched)])
+def pmc_traffic(kind, kernel_names, at_len, batched=False, precision="fp32"):
+    """HBM bytes per launch of a decode kernel from the committed rocprofv3 PMC passes (profiles/r05_pmc_hbm_*summary.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes; separate --pmc runs, scripts/gpu_round5.sh pmc / pmc16 / pmc3).
+    Counters cannot be read inside the timed process.  The attention passes run at a recorded context length (the PMC run starts
+    its decode at --resume-len); its bytes are scaled linearly to `at_len` keys, the length `bytes_per_launch` is quoted at."""
     try:
-        doc = json.load(open(path))
+        rel = next(os.path.join("profiles", f) for f in PMC_SUMMARY[(precision, bool(batched))] if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        doc = json.load(open(os.path.join(ROOT, rel)))
         ks = doc["kernels"]
         def lookup(n):      # rocprofv3 leaves kernels with _Float16 template arguments mangled: match base name + element type
             if n in ks:
@@ -128,7 +132,7 @@ def pmc_traffic(kind, kernel_names, at_len, batched=False):
             if l_pmc > 0:
                 b = b * at_len / l_pmc
                 note = f" (attention measured at mean context {l_pmc:.0f}, scaled x{at_len / l_pmc:.4f} to {at_len} keys)"
-        return {"bytes": round(b), "source": PMC_SUMMARY[bool(batched)] + note}
+        return {"bytes": round(b), "source": rel + note}
     except Exception:
         return {}
 
@@ -455,7 +459,7 @@ def main(argv=None):
     ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
     bytes_per_token = W_ELEMS * esz / B + KV_ELEMS_PER_POS * mean_L * esz
     names = kernel_names(args.precision, B > 4)
-    traffic = pmc_traffic(dom, names.get(dom, []), L_ref, batched=B > 4)
+    traffic = pmc_traffic(dom, names.get(dom, []), L_ref, batched=B > 4, precision=args.precision)
     layer_us = sum(prof[k]["avg_us"] for k in ("qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv", "fc1_gemv", "fc2_gemv"))
     roofline = {
         "bound": "hbm", "kernel": dom, "kernel_name": (names.get(dom) or ["?"])[0], "achieved": round(ach, 1),
@@ -513,8 +517,13 @@ def main(argv=None):
             fprof, fends, fL, _ = decode_kernel_sweep(fast.mesh_decoder, L0, T, NS)
             fends["fit"] = attention_fit(fends["samples"], 2)
             fnames = kernel_names("fp16", False)
+            ftr = pmc_traffic("attn_decode", fnames.get("attn_decode", []), fL, batched=False, precision="fp16")
             out["fast_mode_fp16"].update({
                 "context_len_at_measurement": fL, "context_sweep": fends,
+                "attention": {"kernel_name": (fnames.get("attn_decode") or ["?"])[0], "bytes_per_launch": fprof["attn_decode"]["bytes"],
+                              "avg_us_per_launch": round(fprof["attn_decode"]["avg_us"], 3),
+                              "frac": round(fprof["attn_decode"]["bytes"] / (fprof["attn_decode"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "traffic": ftr.get("bytes"), "traffic_source": ftr.get("source")},
                 "per_layer_kernel_sum_us": round(sum(fprof[k]["avg_us"] for k in ("qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv",
                                                                                   "fc1_gemv", "fc2_gemv")), 2),
                 "kernels": {k: {"avg_us": round(v["avg_us"], 3), "kernel_name": (fnames.get(k) or ["?"])[0],
