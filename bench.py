@@ -258,19 +258,21 @@ def kernel_names(precision, batched):
     nwf = "12" if os.environ.get("ER_NW_FC1", "12" if fast else "4") == "12" else "4"
     qkv = f"gemv_kernel<{wt}, 1, 1, {2 if nwq == '9' else 1}, 1, 3, {nwq}>"
     fc1 = f"gemv_kernel<{wt}, 1, 1, 2, 1, 1, {nwf}>"
+    rw2 = os.environ.get("ER_RW_FC2", "6") if fast else "2"       # fast mode: six rows per fc2 workgroup (er_api.hip, case 5)
+    fc2 = f"gemv_kernel<{wt}, 4, 1, {rw2 if rw2 in ('4', '6') else '2'}, 0, 2, 4>"
     if batched:     # B*16 >= 256: one streaming workgroup per (row, head); smaller batches keep the split round-1 kernel (er_api.hip, kind 1)
         return {"attn_decode": [f"attn_stream_kernel<{wt}, 96, 2>", f"attn_decode_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"]}
     if os.environ.get("ER_DECODE_V", "3") != "2":     # default: balanced chunks, merge fused into out_proj (no merge kernel)
         return {"qkv_gemv": [qkv],
                 "attn_decode": [f"attn_decode3_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}, 16>"],
                 "out_proj_gemv": [f"outproj_merge_kernel<{wt}, 96, 16>"],
-                "fc1_gemv": [fc1], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
+                "fc1_gemv": [fc1], "fc2_gemv": [fc2],
                 "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 0, 4>"], "sample_head": ["sample_head_kernel"]}
     return {"qkv_gemv": [qkv],
             "attn_decode": [f"attn_decode2_kernel<{wt}, 96, {4 if precision == 'fp32' else 2}>"],
             "attn_combine": ["attn_combine2_kernel<96>"],
             "out_proj_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 0, 2, 3>"],
-            "fc1_gemv": [fc1], "fc2_gemv": [f"gemv_kernel<{wt}, 4, 1, 2, 0, 2, 4>"],
+            "fc1_gemv": [fc1], "fc2_gemv": [fc2],
             "lm_head_gemv": [f"gemv_kernel<{wt}, 1, 1, 1, 1, 0, 4>"], "sample_head": ["sample_head_kernel"]}
 
 

@@ -922,6 +922,14 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             }
             if (c->batched && !c->batched_valu) { a.W = L.w2_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st); }   // 48 tiles x 4 K-ranges
             if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);
+            if constexpr (HALF) {
+                // fast mode, one row: FAT workgroups like qkv's and fc1's - 4 or 6 rows per workgroup instead of 2 (384 / 256 workgroups
+                // instead of 768), so that a CU fetches the 24 KB input vector once or twice instead of three times beside its 72 KB of
+                // fp16 weights: fc2 5.60 -> 5.37 us at 6 rows, 5.68 at 4, ids unchanged (profiles/r05_ab_fc2_rows.log; ER_RW_FC2 = 2 / 4 / 6)
+                static const int rw = [] { const char* v = getenv("ER_RW_FC2"); return v ? atoi(v) : 6; }();
+                if (B == 1 && rw == 6) return launch_gemv<WT, 4, 1, 6, PRO_NONE, EPI_RESID>(a, st);
+                if (B == 1 && rw == 4) return launch_gemv<WT, 4, 1, 4, PRO_NONE, EPI_RESID>(a, st);
+            }
             return gemv_groups<WT, 4, 2, PRO_NONE, EPI_RESID>(a, B, I, st);
         }
         case 6: {   // logits = lm_head LN2_last(ypre)

@@ -74,6 +74,8 @@ PY
       find /tmp/prof_dit -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r05_dit_fp16_kernel_stats.csv; head -12 gpurun_out/r05_dit_fp16_kernel_stats.csv | cut -c1-160 ;;
     prefill) { timeout 200 python scripts/prefill_time.py fp16 1,8 2>&1 | filt | tail -2
                timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; } | tee gpurun_out/r05_prefill_time_final.log ;;
+    abfc2)   timeout 900 python scripts/ab_decode.py fp16 2000 rw2= rw4=:ER_RW_FC2=4 rw6=:ER_RW_FC2=6 rw2b= rw4b=:ER_RW_FC2=4 rw6b=:ER_RW_FC2=6 2>&1 | filt | tee gpurun_out/r05_ab_fc2_rows.log ;;
+    abom2)   timeout 900 python scripts/ab_decode.py fp16 2000 rpw1= rpw2=:ER_OM_RPW=2 rpw1b= rpw2b=:ER_OM_RPW=2 2>&1 | filt | tee gpurun_out/r05_ab_om_rpw_fp16.log ;;
     ksplit)  { ER_TEST_CANDIDATES=1 timeout 600 python -m pytest tests -q -m gpu -k candidate -p no:cacheprovider --timeout 400 2>&1 | filt | tail -6
                for K in 0 1 0 1; do echo "ER_FLASH32_KSPLIT=$K"; ER_FLASH32_KSPLIT=$K timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ksplit.log ;;
   esac
