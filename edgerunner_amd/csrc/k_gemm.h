@@ -894,6 +894,9 @@ __global__ __launch_bounds__(ER_WG) void gemm_f32d_mfma_kernel(GemmArgs g, int n
         if (kt + 1 < nk) issue(kt + 1, cur ^ 1);      // lands while this tile is multiplied (4096 MFMA cycles per wave)
         const float* as = lds + cur * STAGE + (wm * 32 * TM + li) * FBK;
         const float* bs = lds + cur * STAGE + GBM * FBK + (wn * 32 * TN + li) * FBK;
+        // (These ds_read_b32 fetches are 4-way bank-conflicted - SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.75, profiles/r05_pmc_sq_prefill.json -
+        // but off the critical path: whole-chunk ds_read_b128 fetches, conflict-free and bit-identical, measured SLOWER, encode + prefill
+        // 38.3 -> 39.2 ms same box, profiles/r05_gemm_f32d_b128.log: twice the LDS bytes and two selects per operand beside 64-cycle MFMAs.)
 #pragma unroll
         for (int kk = 0; kk < FBK / 2; ++kk) {
             const int k = 2 * kk + kh;                                          // kh is 0 / 1: the chunk index is uniform per lane half

@@ -76,6 +76,8 @@ PY
                timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; } | tee gpurun_out/r05_prefill_time_final.log ;;
     abfc2)   timeout 900 python scripts/ab_decode.py fp16 2000 rw2= rw4=:ER_RW_FC2=4 rw6=:ER_RW_FC2=6 rw2b= rw4b=:ER_RW_FC2=4 rw6b=:ER_RW_FC2=6 2>&1 | filt | tee gpurun_out/r05_ab_fc2_rows.log ;;
     abom2)   timeout 900 python scripts/ab_decode.py fp16 2000 rpw1= rpw2=:ER_OM_RPW=2 rpw1b= rpw2b=:ER_OM_RPW=2 2>&1 | filt | tee gpurun_out/r05_ab_om_rpw_fp16.log ;;
+    f32d)    { timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider --timeout 400 -x -k "gemm_f32" 2>&1 | filt | tail -4
+               for L in edgerunner_amd/lib_prev.so edgerunner_amd/libedgerunner_hip.so edgerunner_amd/lib_prev.so edgerunner_amd/libedgerunner_hip.so; do echo "== $L"; ER_LIB_PATH=$ROOT/$L timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_gemm_f32d_b128.log ;;
     ksplit)  { ER_TEST_CANDIDATES=1 timeout 600 python -m pytest tests -q -m gpu -k candidate -p no:cacheprovider --timeout 400 2>&1 | filt | tail -6
                for K in 0 1 0 1; do echo "ER_FLASH32_KSPLIT=$K"; ER_FLASH32_KSPLIT=$K timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ksplit.log ;;
   esac
