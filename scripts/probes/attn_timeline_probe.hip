@@ -60,7 +60,9 @@ __global__ __launch_bounds__(64 * ATTN3_NW) void attn3_timed(AttnDecArgs a) {
     const float* qp = a.q + (long long)b * a.hidden + h * D;
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK, NV = D / (EPL * LPK);
     float qv[NV][EPL];
-    {
+    if constexpr (sizeof(KT) == 2) {
+        hpair_load_q(qp, HPair(threadIdx.x & 63), qv);          // round 5: the fp16 cache's pair mapping
+    } else {
         const int p = threadIdx.x & (LPK - 1);
 #pragma unroll
         for (int j = 0; j < NV; ++j)
@@ -71,10 +73,15 @@ __global__ __launch_bounds__(64 * ATTN3_NW) void attn3_timed(AttnDecArgs a) {
             }
     }
     const int len = NEWENTRY ? (a.fixed_len > 0 ? a.fixed_len : lmem + a.len_add) : len_old;
-    const int clen = NEWENTRY ? ((len + nch - 1) >> __builtin_ctz(nch)) : (len + nch - 1) / nch;
+    int clen = NEWENTRY ? ((len + nch - 1) >> __builtin_ctz(nch)) : (len + nch - 1) / nch;
+    if constexpr (sizeof(KT) == 2) clen = (clen + 1) & ~1;
     const int k0 = c * clen, k1 = min(len, k0 + clen);
     const int nsteps = (k1 - k0 + NW * KPW - 1) / (NW * KPW);
     ER_TP(1);
+    if constexpr (sizeof(KT) == 2) {
+        if (nsteps >= 2) attn3_body_h<D, 2, NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+        else attn3_body_h<D, 1, NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
+    } else
     if (STEPS >= 4 && nsteps >= 4) attn3_body<KT, D, (STEPS >= 4 ? 4 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
     else if (STEPS >= 3 && nsteps == 3) attn3_body<KT, D, (STEPS >= 3 ? 3 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
     else if (STEPS >= 2 && nsteps == 2) attn3_body<KT, D, (STEPS >= 2 ? 2 : 1), NW>(a, kb, vb, qv, k0, k1, ored, wm, wl, po, pml);
