@@ -161,6 +161,70 @@ __global__ __launch_bounds__(ER_WG) void attn_decode_kernel(AttnDecArgs a) {
     const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
     const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
 
+    if constexpr (sizeof(KT) == 2 && D == 96) {
+        // fp16 cache, 192-byte rows: the PAIR mapping (whole 128-byte lines, see above); k0 is a multiple of the chunk = even
+        const HPair hp(lane);
+        const int g8 = lane >> 3;
+        f32x4 kreg[STEPS][3], vreg[STEPS][3];
+        bool vA[STEPS], vB[STEPS];
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kA = k0 + KPS * i + KPW * wid + 2 * g8;
+            vA[i] = kA < k1;
+            vB[i] = kA + 1 < k1;
+            hpair_load(kb, vA[i] ? kA : k0, vB[i] ? kA + 1 : k0, hp, kreg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kA = k0 + KPS * i + KPW * wid + 2 * g8;
+            hpair_load(vb, vA[i] ? kA : k0, vB[i] ? kA + 1 : k0, hp, vreg[i]);
+        }
+        float qh[3][8];
+        hpair_load_q(a.q + (long long)b * a.hidden + h * D, hp, qh);
+        float scA[STEPS], scB[STEPS];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            float sA, sB;
+            hpair_scores(kreg[i], qh, hp, sA, sB);
+            scA[i] = vA[i] ? sA / a.sqrt_d : -INFINITY;
+            scB[i] = vB[i] ? sB / a.sqrt_d : -INFINITY;
+            mloc = fmaxf(mloc, fmaxf(scA[i], scB[i]));
+        }
+        const float m = block_max(mloc, red);     // finite: the chunk holds at least one key
+        float oh[3][8];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[j][e] = 0.f;
+        float lloc = 0.f;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const float pA = vA[i] ? expf(scA[i] - m) : 0.f, pB = vB[i] ? expf(scB[i] - m) : 0.f;
+            if (hp.p == 0) lloc += pA + pB;
+            hpair_accum(vreg[i], pA, pB, hp, oh);
+        }
+        const float l = block_sum(lloc, red);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[j][e] = across_groups_sum<8>(oh[j][e]);        // every 8-lane group now holds the wave's totals
+        float om[8], ohi[8];
+        hpair_fold(oh, hp, om, ohi);
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ored[wid * D + hp.p * 8 + e] = om[e];
+            if (hp.lo) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ored[wid * D + (8 + hp.p) * 8 + e] = ohi[e];
+            }
+        }
+        __syncthreads();
+        float* pout = a.part + (((long long)b * a.H + h) * a.S + s) * (D + 2);
+        if (tid < D) pout[2 + tid] = (ored[tid] + ored[D + tid]) + (ored[2 * D + tid] + ored[3 * D + tid]);
+        if (tid == 0) { pout[0] = m; pout[1] = l; }
+        return;
+    }
     // ---- all loads first: K rows, then V rows (K returns first, V lands while the scores are reduced)
     f32x4 kreg[STEPS][NV], vreg[STEPS][NV];
     bool valid[STEPS];
@@ -279,94 +343,157 @@ __global__ __launch_bounds__(ER_WG) void attn_decode2_kernel(AttnDecArgs a) {
     const KT* kb = reinterpret_cast<const KT*>(a.kcache) + head_off;
     const KT* vb = reinterpret_cast<const KT*>(a.vcache) + head_off;
 
+    if constexpr (sizeof(KT) == 2 && D == 96) {
+        // fp16 cache, 192-byte rows: the PAIR mapping (whole 128-byte lines, see above); k0 is a multiple of the chunk = even
+        const HPair hp(lane);
+        const int g8 = lane >> 3;
+        float qh[3][8];
+        hpair_load_q(a.q + (long long)b * a.hidden + h * D, hp, qh);
+        f32x4 kreg[STEPS][3], vreg[STEPS][3];
+        bool vA[STEPS], vB[STEPS];
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kA = k0 + KPS * i + KPW * wid + 2 * g8;
+            vA[i] = kA < k1;
+            vB[i] = kA + 1 < k1;
+            hpair_load(kb, vA[i] ? kA : k0, vB[i] ? kA + 1 : k0, hp, kreg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kA = k0 + KPS * i + KPW * wid + 2 * g8;
+            hpair_load(vb, vA[i] ? kA : k0, vB[i] ? kA + 1 : k0, hp, vreg[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float scA[STEPS], scB[STEPS];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            float sA, sB;
+            hpair_scores(kreg[i], qh, hp, sA, sB);
+            scA[i] = vA[i] ? sA / a.sqrt_d : -INFINITY;
+            scB[i] = vB[i] ? sB / a.sqrt_d : -INFINITY;
+            mloc = fmaxf(mloc, fmaxf(scA[i], scB[i]));
+        }
+        const float m = wave_max(mloc);           // -inf when the wave holds no valid key
+        float oh[3][8];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[j][e] = 0.f;
+        float lloc = 0.f;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const float pA = vA[i] ? expf(scA[i] - m) : 0.f, pB = vB[i] ? expf(scB[i] - m) : 0.f;
+            if (hp.p == 0) lloc += pA + pB;
+            hpair_accum(vreg[i], pA, pB, hp, oh);
+        }
+        const float l = wave_sum(lloc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[j][e] += row_ror<8>(oh[j][e]);
+        float om[8], ohi[8];
+        hpair_fold(oh, hp, om, ohi);
+        if ((lane & 15) < 8) {
+            float* dst = ored + (wid * 4 + (lane >> 4)) * D;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[hp.p * 8 + e] = om[e];
+            if (hp.lo) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[(8 + hp.p) * 8 + e] = ohi[e];
+            }
+        }
+        if (lane == 0) { wm[wid] = m; wl[wid] = l; }
+    } else {
     // this lane's query elements first: vector loads return in issue order, so anything issued behind the K/V
-    // stream would only become usable after ALL of it has landed
-    float qv[NV][EPL];
-    const float* qp = a.q + (long long)b * a.hidden + h * D;
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < EPL; e += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
-            qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
-        }
-    f32x4 kreg[STEPS][NV], vreg[STEPS][NV];
-    bool valid[STEPS];
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-        const int kk = k0 + KPS * i + KPW * wid + g;
-        valid[i] = kk < k1;
-        const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)(valid[i] ? kk : k0) * D);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) kreg[i][j] = __builtin_nontemporal_load(kr + j * LPK + p);
-    }
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-        const int kk = k0 + KPS * i + KPW * wid + g;
-        const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)(valid[i] ? kk : k0) * D);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) vreg[i][j] = __builtin_nontemporal_load(vr + j * LPK + p);
-    }
-    __builtin_amdgcn_sched_barrier(0);        // every K and V load is issued before the first score is computed
-
-    float sc[STEPS];
-    float mloc = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            float kf[EPL];
-            kv_unpack<KT>(kreg[i][j], kf);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
-        }
-        acc = lane_group_sum<LPK>(acc);
-        sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
-        mloc = fmaxf(mloc, sc[i]);
-    }
-    const float m = wave_max(mloc);           // -inf when the wave holds no valid key (ragged tail of the last chunk)
-
-    float pw[STEPS];
-    float lloc = 0.f;
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-        pw[i] = valid[i] ? expf(sc[i] - m) : 0.f;
-        if (p == 0) lloc += pw[i];
-    }
-    const float l = wave_sum(lloc);
-
-    float o[NV][EPL];
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) o[j][e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i)
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            float vf[EPL];
-            kv_unpack<KT>(vreg[i][j], vf);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
-        }
-    // key groups sit LPK lanes apart: add them inside each row of 16 lanes with DPP rotations (VALU, no LDS crossbar), and
-    // leave the four rows of a wave to the LDS merge below (round 2a did all of it with 36 / 96 ds_bpermutes per lane)
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            o[j][e] += row_ror<8>(o[j][e]);
-            if (LPK == 4) o[j][e] += row_ror<4>(o[j][e]);
-        }
-    if ((lane & 15) < LPK) {
-        float* dst = ored + (wid * 4 + (lane >> 4)) * D;
+        // stream would only become usable after ALL of it has landed
+        float qv[NV][EPL];
+        const float* qp = a.q + (long long)b * a.hidden + h * D;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) dst[(j * LPK + p) * EPL + e] = o[j][e];
+            for (int e = 0; e < EPL; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(qp + (j * LPK + p) * EPL + e);
+                qv[j][e] = t.x; qv[j][e + 1] = t.y; qv[j][e + 2] = t.z; qv[j][e + 3] = t.w;
+            }
+        f32x4 kreg[STEPS][NV], vreg[STEPS][NV];
+        bool valid[STEPS];
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kk = k0 + KPS * i + KPW * wid + g;
+            valid[i] = kk < k1;
+            const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) kreg[i][j] = __builtin_nontemporal_load(kr + j * LPK + p);
+        }
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            const int kk = k0 + KPS * i + KPW * wid + g;
+            const f32x4* vr = reinterpret_cast<const f32x4*>(vb + (long long)(valid[i] ? kk : k0) * D);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) vreg[i][j] = __builtin_nontemporal_load(vr + j * LPK + p);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // every K and V load is issued before the first score is computed
+
+        float sc[STEPS];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float kf[EPL];
+                kv_unpack<KT>(kreg[i][j], kf);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc = fmaf(qv[j][e], kf[e], acc);
+            }
+            acc = lane_group_sum<LPK>(acc);
+            sc[i] = valid[i] ? acc / a.sqrt_d : -INFINITY;
+            mloc = fmaxf(mloc, sc[i]);
+        }
+        const float m = wave_max(mloc);           // -inf when the wave holds no valid key (ragged tail of the last chunk)
+
+        float pw[STEPS];
+        float lloc = 0.f;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            pw[i] = valid[i] ? expf(sc[i] - m) : 0.f;
+            if (p == 0) lloc += pw[i];
+        }
+        const float l = wave_sum(lloc);
+
+        float o[NV][EPL];
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[j][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float vf[EPL];
+                kv_unpack<KT>(vreg[i][j], vf);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[j][e] = fmaf(pw[i], vf[e], o[j][e]);
+            }
+        // key groups sit LPK lanes apart: add them inside each row of 16 lanes with DPP rotations (VALU, no LDS crossbar), and
+        // leave the four rows of a wave to the LDS merge below (round 2a did all of it with 36 / 96 ds_bpermutes per lane)
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                o[j][e] += row_ror<8>(o[j][e]);
+                if (LPK == 4) o[j][e] += row_ror<4>(o[j][e]);
+            }
+        if ((lane & 15) < LPK) {
+            float* dst = ored + (wid * 4 + (lane >> 4)) * D;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dst[(j * LPK + p) * EPL + e] = o[j][e];
+        }
+        if (lane == 0) { wm[wid] = m; wl[wid] = l; }
     }
-    if (lane == 0) { wm[wid] = m; wl[wid] = l; }
     __syncthreads();
     if (tid < D) {
         const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));   // finite: the chunk holds at least one key
