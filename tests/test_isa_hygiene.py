@@ -147,3 +147,21 @@ def test_prefill_tail_gemvs_are_in_the_code_object(kernels):
             assert sel, (ks, nb, rw, epi)       # (select() asserts too: an instantiation that is gone must not pass vacuously)
             for n, b in sel.items():
                 assert not [l for l in b if l.startswith("scratch_")], (n, "scratch access")
+
+
+def test_gemm_hh256_main_loop_shape(kernels):
+    """The 256 x 256 / 8-wave LDS-DMA GEMM (k_gemm.h, round 5): no scratch at 200+ registers, the k-loop's 32 MFMAs fed by 24
+    fragment reads with at most two full lgkmcnt(0) drains in front of MFMAs (fragments double-buffered: left alone hipcc put one in
+    front of every four MFMAs), eight asm LDS-DMA pieces per k-step and ONE counted wait + raw barrier - no compiler-issued
+    vmcnt wait anywhere in the loop (the pieces are invisible to its bookkeeping)."""
+    for n, b in select(kernels, r"gemm_hh256_kernel").items():
+        assert not [l for l in b if l.startswith("scratch_")], (n, "scratch access")
+        mf = [i for i, l in enumerate(b) if l.startswith("v_mfma_f32_32x32x16_f16")]
+        assert len(mf) == 32, (n, len(mf))
+        loop = b[mf[0] - 40:mf[-1] + 6]
+        assert count(loop, "ds_read_b128") == 24, (n, count(loop, "ds_read_b128"))
+        drains = [l for l in loop if l.startswith("s_waitcnt") and "lgkmcnt(0)" in l and "vmcnt" not in l]
+        assert len(drains) <= 2, (n, drains)
+        vm = [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l]
+        assert vm == ["s_waitcnt vmcnt(0) lgkmcnt(0)"], (n, vm)
+        assert count(b, "global_load_lds_dwordx4") == 16, (n, "8 pieces in the prologue + 8 in the loop")
