@@ -1734,6 +1734,32 @@ extern "C" int er_k_gemm_hh_qkv(const float* a, const void* w, const float* bias
     return ER_OK;
 }
 
+extern "C" int er_k_gemm_hh_geglu(const float* a, const void* w, const float* bias, void* out16, int m, int f, int k, int force_tile,
+                                  void* stream) {
+    // out16[m][f] = fp16(GEGLU(fp16(a) . w^T + bias)), w = the [2f][k] fp16 weight in the checkpoint's order (value rows, then gate rows):
+    // the entry builds the permuted copy the product keeps per layer (geglu_permute_kernel) and runs the fused kernel
+    if (k % 64 || f % 64 || m <= 0) return fail(ER_ERR_INVALID, "er_k_gemm_hh_geglu: k and f must be multiples of 64");
+    if (force_tile != 0 && force_tile != 1 && force_tile != 2 && force_tile != 4) return fail(ER_ERR_INVALID, "er_k_gemm_hh_geglu: force_tile 0 / 1 / 2 / 4");
+    hipStream_t st = (hipStream_t)stream;
+    _Float16 *a16 = nullptr, *wp = nullptr;
+    float* bp = nullptr;
+    HIPCHK(hipMalloc(&a16, (size_t)m * k * sizeof(_Float16)));
+    HIPCHK(hipMalloc(&wp, (size_t)2 * f * k * sizeof(_Float16)));
+    HIPCHK(hipMalloc(&bp, (size_t)2 * f * sizeof(float)));
+    hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)m * k)), dim3(ER_WG), 0, st, a, a16, (long long)m, k, k, k);
+    hipLaunchKernelGGL(geglu_permute_kernel, dim3(2 * f), dim3(ER_WG), 0, st, reinterpret_cast<const _Float16*>(w), bias, wp, bp, f, k);
+    GemmArgs g = gemm_args_default();
+    g.A = reinterpret_cast<const float*>(a16); g.B = reinterpret_cast<const float*>(wp); g.bias = bp;
+    g.M = m; g.N = 2 * f; g.K = k; g.lda = k; g.ldb = k; g.ldc = 2 * f; g.ldr = 2 * f;
+    g.c16 = reinterpret_cast<_Float16*>(out16); g.ldc16 = f;
+    hipError_t e = launch_gemm_hh_geglu(g, st, force_tile);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(a16); hipFree(wp); hipFree(bp);
+    HIPRET(e);
+    HIPRET(e2);
+    return ER_OK;
+}
+
 extern "C" int er_k_gemm_f16s(const float* a, const void* w, const float* bias, const float* resid, float* cc, int m, int n, int k,
                               int lda, int ldb, int ldc, int relu, void* stream) {
     if (k % 32) return fail(ER_ERR_INVALID, "er_k_gemm_f16s: k must be a multiple of 32");

@@ -1043,16 +1043,18 @@ __global__ __launch_bounds__(ER_WG) void geglu_permute_kernel(const _Float16* w,
 
 // out16[M][F] = fp16(GEGLU(A . Wp^T + bp)): Wp / bp = the [2F][K] weight / [2F] bias permuted by gemm_hh_geglu_row (g.B, g.bias),
 // g.N = 2F (a multiple of 128), g.c16 = out16; no fp32 output
-inline hipError_t launch_gemm_hh_geglu(const GemmArgs& g, hipStream_t st) {
+// force_tile (unit tests): 0 = the product rule, 1 = 128 x 128, 2 = 64 x 128 (4 waves), 4 = 256 x 256 (8 waves; N % 256 == 0)
+inline hipError_t launch_gemm_hh_geglu(const GemmArgs& g, hipStream_t st, int force_tile = 0) {
     if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7) || (g.N & 127) || !g.c16 || !g.bias) return hipErrorInvalidValue;
-    if ((g.N & 255) == 0 && gemm_hh_use_256(g.M, g.N)) {
+    if (force_tile == 4 && (g.N & 255)) return hipErrorInvalidValue;
+    if (force_tile == 4 || (force_tile == 0 && (g.N & 255) == 0 && gemm_hh_use_256(g.M, g.N))) {
         const int ntx4 = g.N / 256;
         const dim3 grid4(ntx4 * ((g.M + 255) / 256));
         hipLaunchKernelGGL((gemm_hh256_kernel<HEPI_GEGLU>), grid4, dim3(X256_THREADS), 0, st, g, ntx4);
         return hipGetLastError();
     }
     const int ntx = g.N / 128;
-    if ((long long)((g.M + 127) / 128) * ntx >= 768) {
+    if (force_tile == 1 || (force_tile == 0 && (long long)((g.M + 127) / 128) * ntx >= 768)) {
         hipLaunchKernelGGL((gemm_hh_mfma_kernel<2, 2, HEPI_GEGLU>), dim3(ntx * ((g.M + 127) / 128)), dim3(ER_WG), 0, st, g, ntx);
     } else {
         hipLaunchKernelGGL((gemm_hh_mfma_kernel<1, 2, HEPI_GEGLU>), dim3(ntx * ((g.M + 63) / 64)), dim3(ER_WG), 0, st, g, ntx);

@@ -104,6 +104,17 @@ def gemm_hh_qkv(a, w_half, bias, rows_per_batch, force_tile=0):
     return qk16, vt
 
 
+def gemm_hh_geglu(a, w_half, bias, force_tile=0):
+    """fp16(GEGLU(fp16(a) . W^T + b)) through the fused LDS-DMA kernel; w_half [2F, K] fp16 in checkpoint order (value rows, gate rows)."""
+    lib = native.load_library()
+    M, K = a.shape
+    F = w_half.shape[0] // 2
+    out = torch.empty((M, F), dtype=torch.float16, device=a.device)
+    native.check(lib.er_k_gemm_hh_geglu(native.ptr(a.contiguous()), native.ptr(w_half.contiguous()), native.ptr(bias), native.ptr(out), M, F, K,
+                                        force_tile, _st()), "er_k_gemm_hh_geglu")
+    return out
+
+
 def gemm_f16s(a, w_half, bias=None, resid=None, relu=False):
     """C = relu?(fp16(A) . W^T + bias) (+resid) on the fp16-input MFMA path; a fp32 [M,K], w_half fp16 [N,K]."""
     lib = native.load_library()

@@ -30,7 +30,7 @@ EXPORTS = [
     "er_meto_decode", "er_meto_encode", "er_dit_create", "er_dit_destroy", "er_dit_load_tensor",
     "er_dit_finalize_weights", "er_dit_project_cond", "er_dit_encode_image", "er_dit_forward", "er_dit_sample",
     "er_set_row_streams", "er_plan_decode", "er_ctx_plan", "er_plan_gemm_tile", "er_kernel_kind_name", "er_profile_decode_kernels", "er_profile_decode_kernels_at", "er_last_decode_ms",
-    "er_k_gemv", "er_k_attn_decode", "er_k_attn_outproj3", "er_k_gemm", "er_k_gemm_f16", "er_k_gemm_hh", "er_k_gemm_hh_qkv", "er_k_gemm_f16s", "er_k_flash_attn_f16", "er_k_flash_attn_hh", "er_k_flash_attn_f32", "er_k_flash_attn_f16s", "er_k_layernorm", "er_k_softmax", "er_k_sample_head",
+    "er_k_gemv", "er_k_attn_decode", "er_k_attn_outproj3", "er_k_gemm", "er_k_gemm_f16", "er_k_gemm_hh", "er_k_gemm_hh_qkv", "er_k_gemm_hh_geglu", "er_k_gemm_f16s", "er_k_flash_attn_f16", "er_k_flash_attn_hh", "er_k_flash_attn_f32", "er_k_flash_attn_f16s", "er_k_layernorm", "er_k_softmax", "er_k_sample_head",
 ]
 
 
@@ -120,6 +120,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.er_k_gemm_f16s.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.er_k_gemm_hh.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     lib.er_k_gemm_hh_qkv.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.er_k_gemm_hh_geglu.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.er_k_flash_attn_f16.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.er_k_flash_attn_hh.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.er_k_flash_attn_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]

@@ -286,6 +286,12 @@ int er_k_gemm_hh(const float* a_dev, const void* w_half_dev, const float* bias_d
  * 64x128 / 64x64 tiles (4 waves), 4 = 256x256 (8 waves). */
 int er_k_gemm_hh_qkv(const float* a_dev, const void* w_half_dev, const float* bias_dev, void* qk16_out_dev, void* vt_out_dev, int m,
                      int n, int k, int rows_per_batch, int force_tile, void* stream);
+/* the GEGLU feed-forward-in of the DiT block (core/transformer/dit.py FeedForward: x, gate = Linear(h).chunk(2); x * gelu(gate),
+ * erf form) as the LDS-DMA kernels run it: out16[m][f] = fp16((fp16(a) . Wx^T + bx) * gelu(fp16(a) . Wg^T + bg)) with w_half_dev the
+ * [2 f][k] fp16 weight in checkpoint order; the [m][2 f] pre-activation never reaches HBM.  force_tile 0 = the product rule,
+ * 1 / 2 = 128x128 / 64x128 tiles (4 waves), 4 = 256x256 (8 waves, f % 128 == 0): all forms are bit-identical. */
+int er_k_gemm_hh_geglu(const float* a_dev, const void* w_half_dev, const float* bias_dev, void* out16_dev, int m, int f, int k,
+                       int force_tile, void* stream);
 int er_k_gemm_f16s(const float* a, const void* w_half, const float* bias, const float* resid, float* c, int m, int n, int k,
                    int lda, int ldb, int ldc, int relu, void* stream);
 /* softmax(q k^T / 8) v, head_dim 64, non-causal, fp16 operands / fp32 accumulate; q,o [B,N,H*64], k,v [B,M,H*64] fp32 */

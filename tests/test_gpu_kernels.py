@@ -350,6 +350,22 @@ def test_gemm_hh_lds_dma(M, N, K):
         assert torch.equal(K_.gemm_hh(eye, wq), wq.float().T.contiguous()), "I . W^T must reproduce W^T exactly"
 
 
+@pytest.mark.parametrize("M,F,K", [(4096, 4096, 1024), (300, 128, 192), (2050, 512, 64)])
+def test_gemm_hh_geglu_fused_epilogue(M, F, K):
+    """The DiT block's feed-forward-in with GEGLU fused into the GEMM epilogue (core/transformer/dit.py FeedForward): fp16 output of
+    (x + bx) * gelu_erf(gate + bg) from the permuted-weight product; against float64 torch on the fp16-rounded operands, and
+    BIT-EQUAL across the three kernel forms (4 waves 128 x 128 / 64 x 128, 8 waves 256 x 256 - the one the DiT runs at M = 4096)."""
+    from edgerunner_amd import kernels as K_
+    a, w, bias = rnd(M, K, seed=95), rnd(2 * F, K, seed=96, scale=0.05), rnd(2 * F, seed=97)
+    wh = w.half()
+    pre = a.half().double() @ wh.double().T + bias.double()
+    ref = pre[:, :F] * torch.nn.functional.gelu(pre[:, F:])
+    outs = {t: K_.gemm_hh_geglu(a, wh, bias, force_tile=t) for t in ((0, 1, 2, 4) if F % 128 == 0 else (0, 1, 2))}
+    close(outs[0].double(), ref, 2e-3, 2e-3, "GEGLU GEMM (fp16 output)")
+    for t, o in outs.items():
+        assert torch.equal(o, outs[1]), f"tile form {t} differs from the 128 x 128 form"
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,rows,heads,K", [(4096, 2048, 16, 1024), (256, 64, 2, 64), (384, 128, 4, 192)])
 def test_gemm_hh_qkv_writes_v_transposed(M, rows, heads, K, tile):
