@@ -464,7 +464,8 @@ def test_flash_attn_f32(B, H, N, M, D, causal):
     close(o, ref, 5e-6, 2e-5, "fp32 flash attention")
 
 
-@pytest.mark.parametrize("B,H,N,M", [(1, 16, 2050, 2050), (1, 2, 100, 100), (1, 2, 70, 200), (1, 1, 1, 1), (1, 3, 64, 64), (1, 2, 129, 129)])
+@pytest.mark.parametrize("B,H,N,M", [(1, 16, 2050, 2050), (2, 16, 2050, 2050), (3, 4, 300, 300), (1, 2, 100, 100), (1, 2, 70, 200), (1, 1, 1, 1),
+                                     (1, 3, 64, 64), (1, 2, 129, 129)])
 def test_flash_attn_f32_key_range_split(B, H, N, M, monkeypatch):
     """The causal head_dim-96 prefill attention of a single prefix runs as two workgroups per query tile, each walking one half of
     its key tiles, + flash32_merge_kernel (k_flash_attn_f32.h, KSP; default since round 5, ER_FLASH32_KSPLIT=0 = the unsplit
