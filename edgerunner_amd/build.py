@@ -16,8 +16,11 @@ SRC = os.path.join(PKG, "csrc", "er_api.hip")
 LIB = os.path.join(PKG, "libedgerunner_hip.so")
 # -amdgpu-kernarg-preload-count: leading SCALAR kernel arguments arrive in SGPRs at wave launch (the single-row decode kernels lead
 # their argument lists with the pointers their first loads need: csrc/k_gemv.h)
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified; no kernel of the library needs more than
+# its arch-VGPR budget for them): the softmax / epilogue VALU work reads them in place instead of through v_accvgpr_read / _write copies
+# (flash_attn_hh_kernel: 224 of its 1350 instructions; guided DiT forward 9.02 -> 8.73 ms same box, profiles/r05_ab_mfma_vgpr_form.log)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=16",
-         "-shared", "-fPIC"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form", "-shared", "-fPIC"]
 
 
 def sources():
