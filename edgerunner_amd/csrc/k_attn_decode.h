@@ -1019,6 +1019,7 @@ __device__ __forceinline__ void attn_stream_reduce(const AttnTile<KT, D, STEPS>&
 
 template <typename KT, int D, int STEPS>
 __global__ __launch_bounds__(ER_WG) void attn_stream_kernel(AttnDecArgs a) {
+    static_assert(sizeof(KT) != 2 || D == 96, "fp16 cache: the pair mapping of this kernel is written for 192-byte rows");
     constexpr int EPL = KVec<KT>::EPL, LPK = KVec<KT>::LPK;
     constexpr int NV = D / (EPL * LPK);
     constexpr int KPW = 64 / LPK;
