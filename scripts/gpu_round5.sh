@@ -91,6 +91,9 @@ PY
     abfc232) timeout 900 python scripts/ab_decode.py fp32 2000 rw2= rw3=:ER_RW_FC2_F32=3 rw4=:ER_RW_FC2_F32=4 rw2b= rw3b=:ER_RW_FC2_F32=3 rw4b=:ER_RW_FC2_F32=4 2>&1 | filt | tee gpurun_out/r05_ab_fc2_rows_fp32.log ;;
     dittile) { for E in "" "ER_GEMM256_MIN_TILES=192" "ER_GEMM_HH_TILE=1" "ER_GEMM_HH_TILE=2" "ER_GEMM_HH_TILE=3" "" "ER_GEMM256_MIN_TILES=192" "ER_GEMM256_MIN_TILES=64"; do echo "== $E"; env $E timeout 300 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_dit_tile_rules.log ;;
     abvf)    { for L in edgerunner_amd/libedgerunner_hip.so edgerunner_amd/lib_vf.so edgerunner_amd/libedgerunner_hip.so edgerunner_amd/lib_vf.so; do echo "== $L"; ER_LIB_PATH=$ROOT/$L timeout 300 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1; ER_LIB_PATH=$ROOT/$L timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; ER_LIB_PATH=$ROOT/$L timeout 200 python scripts/prefill_time.py fp16 1,8 2>&1 | filt | tail -2; done; } | tee gpurun_out/r05_ab_mfma_vgpr_form.log ;;
+    abilp)   { timeout 600 python scripts/ab_decode.py fp32 2000 base= ilp=edgerunner_amd/lib_ilp.so 2>&1 | filt
+               timeout 600 python scripts/ab_decode.py fp16 2000 base= ilp=edgerunner_amd/lib_ilp.so 2>&1 | filt
+               for L in edgerunner_amd/libedgerunner_hip.so edgerunner_amd/lib_ilp.so; do echo "== $L"; ER_LIB_PATH=$ROOT/$L timeout 300 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1; ER_LIB_PATH=$ROOT/$L timeout 300 python scripts/bench_batch.py 32 600 1000 fp16 2>&1 | filt | grep aggregate | cut -c1-200; ER_LIB_PATH=$ROOT/$L timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ab_sched_max_ilp.log ;;
     ksplit)  { ER_TEST_CANDIDATES=1 timeout 600 python -m pytest tests -q -m gpu -k candidate -p no:cacheprovider --timeout 400 2>&1 | filt | tail -6
                for K in 0 1 0 1; do echo "ER_FLASH32_KSPLIT=$K"; ER_FLASH32_KSPLIT=$K timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ksplit.log ;;
   esac
