@@ -94,6 +94,8 @@ PY
     abilp)   { timeout 600 python scripts/ab_decode.py fp32 2000 base= ilp=edgerunner_amd/lib_ilp.so 2>&1 | filt
                timeout 600 python scripts/ab_decode.py fp16 2000 base= ilp=edgerunner_amd/lib_ilp.so 2>&1 | filt
                for L in edgerunner_amd/libedgerunner_hip.so edgerunner_amd/lib_ilp.so; do echo "== $L"; ER_LIB_PATH=$ROOT/$L timeout 300 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1; ER_LIB_PATH=$ROOT/$L timeout 300 python scripts/bench_batch.py 32 600 1000 fp16 2>&1 | filt | grep aggregate | cut -c1-200; ER_LIB_PATH=$ROOT/$L timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ab_sched_max_ilp.log ;;
+    abfa8)   { timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_dit.py -q -m gpu -p no:cacheprovider --timeout 600 -x -k "flash_attn_hh or dit or DiT or forward or sampler or latents" 2>&1 | filt | tail -4
+               for W in 4 8 4 8; do echo "== ER_FA_HH_WAVES=$W"; ER_FA_HH_WAVES=$W timeout 300 python scripts/bench_dit.py 16 10 fp16 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ab_fa_hh_waves.log ;;
     ksplit)  { ER_TEST_CANDIDATES=1 timeout 600 python -m pytest tests -q -m gpu -k candidate -p no:cacheprovider --timeout 400 2>&1 | filt | tail -6
                for K in 0 1 0 1; do echo "ER_FLASH32_KSPLIT=$K"; ER_FLASH32_KSPLIT=$K timeout 200 python scripts/prefill_time.py fp32 1 2>&1 | filt | tail -1; done; } | tee gpurun_out/r05_ksplit.log ;;
   esac
