@@ -46,10 +46,10 @@ LAUNCHES_PER_TOKEN = {"qkv_gemv": 24, "attn_decode": 24, "attn_combine": 24, "ou
                       "fc2_gemv": 24, "lm_head_gemv": 1, "sample_head": 1}
 # committed rocprofv3 PMC summaries (scripts/gpu_round4.sh pmc / pmc3): single-row decode kernels, batched (B = 32) decode kernels
 # committed PMC summaries, newest round first (a file that is not there yet falls through to the previous round's)
-PMC_SUMMARY = {("fp32", False): ["r05_pmc_hbm_summary.json", "r04_pmc_hbm_summary.json"],
-               ("fp16", False): ["r05_pmc_hbm_fp16_summary.json"],
-               ("fp16", True): ["r05_pmc_hbm_config3_summary.json", "r04_pmc_hbm_config3_summary.json"],
-               ("fp32", True): []}
+PMC_SUMMARY = {("fp32", False): ["r06_pmc_hbm_summary.json", "r05_pmc_hbm_summary.json", "r04_pmc_hbm_summary.json"],
+               ("fp16", False): ["r06_pmc_hbm_fp16_summary.json", "r05_pmc_hbm_fp16_summary.json"],
+               ("fp16", True): ["r06_pmc_hbm_config3_summary.json", "r05_pmc_hbm_config3_summary.json", "r04_pmc_hbm_config3_summary.json"],
+               ("fp32", True): ["r06_pmc_hbm_config3_exact_summary.json"]}
 # the single-GPU configurations of BASELINE.json (configs[0] is the CPU path = cpu_baseline; configs[4] = dit_front_end_fp16)
 CONFIGS = {
     1: {"name": "BASELINE configs[1]", "batch": 1, "num_face": 1000, "mode": "greedy", "precision": "fp32"},
@@ -349,6 +349,72 @@ def decode_kernel_sweep(dec, L0, T, NS, repeats_mean=6):
     return prof, ends, L_ref, mean_L
 
 
+def roofline_block(prof, ends, L_ref, mean_L, L0, T, NS, B, precision, decode_only_per_gpu):
+    """`roofline` object of a bench line from a kernel sweep: the dominant decode kernel as a run average + the per-kind table."""
+    esz = 4 if precision == "fp32" else 2
+    per_token_us = {k: v["avg_us"] * LAUNCHES_PER_TOKEN[k] for k, v in prof.items()}
+    dom = max(per_token_us, key=per_token_us.get)
+    ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
+    bytes_per_token = W_ELEMS * esz / B + KV_ELEMS_PER_POS * mean_L * esz
+    names = kernel_names(precision, B > 4)
+    traffic = pmc_traffic(dom, names.get(dom, []), L_ref, batched=B > 4, precision=precision)
+    layer_us = sum(prof[k]["avg_us"] for k in ("qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv", "fc1_gemv", "fc2_gemv"))
+    return {
+        "bound": "hbm", "kernel": dom, "kernel_name": (names.get(dom) or ["?"])[0], "achieved": round(ach, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+        "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"),
+        "bytes_per_launch": prof[dom]["bytes"], "avg_us_per_launch": round(prof[dom]["avg_us"], 3),
+        "context_len_at_measurement": L_ref,
+        "note": f"run-average: mean launch duration over {NS} contexts spread over the timed run (contexts {L0 + 1}..{L0 + T}) and "
+                "the algorithmic bytes of one launch at the mean context length; reproduce with scripts/roofline_from_rocprof.py "
+                "on profiles/r06_*_kernel_stats.csv",
+        "context_sweep": ends,
+        "per_layer_kernel_sum_us": round(layer_us, 2),
+        "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1) if v["avg_us"] > 0 else 0.0,
+                        "us_per_token": round(per_token_us[k], 2)} for k, v in prof.items()},
+        "whole_step": {"bytes_per_token": bytes_per_token,
+                       "achieved_GBps": round(decode_only_per_gpu * bytes_per_token / 1e9, 1),
+                       "frac": round(decode_only_per_gpu * bytes_per_token / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+
+def first_divergence(ids_a, ids_b):
+    """Per row: index of the first position where two id streams differ (len = never)."""
+    out = []
+    for a, b in zip(ids_a, ids_b):
+        a, b = np.asarray(a), np.asarray(b)
+        n = min(len(a), len(b))
+        d = np.nonzero(a[:n] != b[:n])[0]
+        out.append(int(d[0]) if len(d) else n)
+    return out
+
+
+def config3_shard_extra(lmm, dev, points, num_face, T, precision, tok, NS=8):
+    """ONE full-size step of BASELINE configs[3]'s per-GPU shard (32 clouds, greedy, T = 4 * num_face tokens) on an existing context,
+    under the same clock as the headline: encode + prefill + decode + detokenise (clean=True, the reference's default), with its own
+    roofline block.  A 32-token run first builds the B = 32 context (cache reservation, tiled weight copies, the step graph)."""
+    import torch
+    from edgerunner_amd import weights as W
+    Bx = 32
+    pcs = torch.cat([W.synthetic_point_cloud(i, points) for i in range(Bx)]).to(dev)
+    lmm.generate(pcs, num_face, tokenizer=object(), max_new_tokens=32, min_new_tokens=32)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    meshes, toks = lmm.generate(pcs, num_face, tokenizer=tok, max_new_tokens=T, min_new_tokens=T, clean=True)
+    torch.cuda.synchronize()
+    step_s = time.perf_counter() - t
+    dec = lmm.mesh_decoder
+    dec_tok_s = Bx * T / (dec.last_decode_ms / 1e3)
+    prof, ends, L_ref, mean_L = decode_kernel_sweep(dec, PREFIX, T, NS, repeats_mean=3)
+    ends["fit"] = attention_fit(ends["samples"], 4 if precision == "fp32" else 2)
+    return {"workload": f"BASELINE configs[3] shard at full size: 32 clouds in one batch on one GPU, greedy, test_num_face={num_face}, {T} new "
+                        f"tokens per cloud, {'exact fp32 (ids bit-exact vs the CPU reference)' if precision == 'fp32' else 'fp16 storage / fp32 accumulate'}; "
+                        "one step = encode_cond + 2050-token prefill + decode + detokenise (clean=True)",
+            "value": round(Bx * T / step_s, 1), "unit": "tokens/s", "ms_per_step": round(step_s * 1e3, 1), "steps": 1,
+            "decode_only_tokens_per_s": round(dec_tok_s, 1), "faces_first_mesh": int(len(meshes[0].faces)) if meshes and meshes[0] is not None else None,
+            "roofline": roofline_block(prof, ends, L_ref, mean_L, PREFIX, T, NS, Bx, precision, dec_tok_s)}, toks
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -397,12 +463,17 @@ def main(argv=None):
             body += [3 + (len(body) // 4) % 2] + [6 + ((len(body) + i) * 53) % 512 for i in range(3)]
         resume = torch.tensor([body[: args.resume_len]] * B, dtype=torch.long)
     n_items = world * B
+    # the whole LMM.generate() is timed, detokenise included (core/models.py:309-319, core/provider.py:39-66): ids -> mesh through the
+    # native meto engine + the trimesh-style clean-up (clean=True is the reference's default); its cost is also reported by itself
+    from edgerunner_amd.meto import Engine, save_mesh
+    tok_engine = Engine(opt.discrete_bins, backend=opt.meto_backend)
 
     def one_step(step_idx):
         mine = D.shard_indices(n_items, rank, world)        # cloud index i runs on rank i mod world
         pcs = torch.cat([W.synthetic_point_cloud(step_idx * n_items + i, args.points) for i in mine]).to(dev)   # resident in HBM
-        _, toks = lmm.generate(pcs, args.num_face, tokenizer=object(), max_new_tokens=T, min_new_tokens=T, resume_ids=resume,
-                               seed=(1000 + step_idx) if args.mode == "sample" else None)
+        _, toks = lmm.generate(pcs, args.num_face, tokenizer=tok_engine, max_new_tokens=T, min_new_tokens=T, resume_ids=resume,
+                               seed=(1000 + step_idx) if args.mode == "sample" else None, clean=True)
+        last_tokens[:] = [toks[0]]
         torch.cuda.synchronize()
         tg = time.perf_counter()
         streams = D.gather_token_streams([t[args.resume_len:] for t in toks], n_items, device=dev)
@@ -415,6 +486,7 @@ def main(argv=None):
             print(f"[bench +{time.time() - t0:.1f}s] {msg}", file=sys.stderr, flush=True)
 
     gather_ms = []
+    last_tokens = []
     for w in range(args.warmup):
         one_step(-1 - w)
     log("warmup done")
@@ -456,30 +528,15 @@ def main(argv=None):
     prof, ends, L_ref, mean_L = decode_kernel_sweep(lmm.mesh_decoder, L0, T, NS)
     ends["fit"] = attention_fit(ends["samples"], esz)
     log("kernel sweep done")
-    per_token_us = {k: v["avg_us"] * LAUNCHES_PER_TOKEN[k] for k, v in prof.items()}
-    dom = max(per_token_us, key=per_token_us.get)
-    ach = prof[dom]["bytes"] / (prof[dom]["avg_us"] * 1e-6) / 1e9
-    bytes_per_token = W_ELEMS * esz / B + KV_ELEMS_PER_POS * mean_L * esz
-    names = kernel_names(args.precision, B > 4)
-    traffic = pmc_traffic(dom, names.get(dom, []), L_ref, batched=B > 4, precision=args.precision)
-    layer_us = sum(prof[k]["avg_us"] for k in ("qkv_gemv", "attn_decode", "attn_combine", "out_proj_gemv", "fc1_gemv", "fc2_gemv"))
-    roofline = {
-        "bound": "hbm", "kernel": dom, "kernel_name": (names.get(dom) or ["?"])[0], "achieved": round(ach, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-        "traffic": traffic.get("bytes"), "traffic_source": traffic.get("source"),
-        "bytes_per_launch": prof[dom]["bytes"], "avg_us_per_launch": round(prof[dom]["avg_us"], 3),
-        "context_len_at_measurement": L_ref,
-        "note": f"run-average: mean launch duration over {NS} contexts spread over the timed run (contexts {L0 + 1}..{L0 + T}) and "
-                "the algorithmic bytes of one launch at the mean context length; reproduce with scripts/roofline_from_rocprof.py "
-                "on profiles/r05_*_kernel_stats.csv",
-        "context_sweep": ends,
-        "per_layer_kernel_sum_us": round(layer_us, 2),
-        "kernels": {k: {"avg_us": round(v["avg_us"], 3), "GBps": round(v["bytes"] / (v["avg_us"] * 1e-6) / 1e9, 1) if v["avg_us"] > 0 else 0.0,
-                        "us_per_token": round(per_token_us[k], 2)} for k, v in prof.items()},
-        "whole_step": {"bytes_per_token": bytes_per_token,
-                       "achieved_GBps": round(decode_only / world * bytes_per_token / 1e9, 1),
-                       "frac": round(decode_only / world * bytes_per_token / 1e9 / HBM_PEAK_GBS, 4)},
-    }
+    roofline = roofline_block(prof, ends, L_ref, mean_L, L0, T, NS, B, args.precision, decode_only / world)
+    # detokenise by itself (host): the stream of the last timed step, both forms of the clean flag
+    detok = {}
+    if last_tokens:
+        for clean in (False, True):
+            td = time.perf_counter()
+            for _ in range(5):
+                save_mesh(last_tokens[0], opt, tokenizer=tok_engine, clean=clean)
+            detok["clean" if clean else "raw"] = round((time.perf_counter() - td) / 5 * 1e3, 3)
 
     cfg_name = CONFIGS[args.config]["name"] + (f" with {', '.join(args.overridden)} overridden" if args.overridden else "")
     out = {
@@ -491,16 +548,28 @@ def main(argv=None):
         "config": {"workload": f"{cfg_name}: ArAE random-init (seeded synthetic checkpoint), batch {B} per GPU, "
                                f"{'greedy' if args.mode == 'greedy' else 'sample mode (top-k 10, Philox inverse-CDF draw on the device)'}, "
                                f"test_num_face={args.num_face}, {T} new tokens (EOS suppressed until T), "
-                               f"{args.points}-point synthetic cloud; step = encode_cond + {L0}-token prefill + {T}-token decode"
+                               f"{args.points}-point synthetic cloud; step = the whole LMM.generate(): encode_cond + {L0}-token prefill + "
+                               f"{T}-token decode + detokenise to a mesh (native meto engine, clean=True)"
                                f"{' + RCCL all-gather of token streams' if world > 1 else ''}",
                    "baseline_config": args.config, "layers": args.layers, "hidden": 1536, "heads": 16, "tokens_per_sample": T,
                    "batch_per_gpu": B, "generate_mode": args.mode, "precision": args.precision,
                    "parallelism": f"dp{world} (independent samples, full replica per GPU)"},
         "decode_only_tokens_per_s": round(decode_only, 2),
+        "detokenise_ms": {"per_sample_clean_true": detok.get("clean"), "per_sample_clean_false": detok.get("raw"),
+                          "note": "host time of save_mesh (ids -> vertices / faces, core/provider.py:39-66) for one 4000-token stream; INSIDE the timed "
+                                  "step with clean=True"},
         "per_rank": per_rank,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and args.config == 1 and not args.overridden and not args.no_fast_extra:
+        # BASELINE configs[3]'s shard (32 clouds per GPU) at FULL size in the exact mode - the mode whose greedy ids are bit-exact vs the
+        # CPU reference (tests/test_gpu_parity.py::test_config4_shard_B32_T4000_row0_bit_exact) - on the headline's own context
+        exact_toks = None
+        try:
+            out["config3_shard_exact_fp32"], exact_toks = config3_shard_extra(lmm, dev, args.points, args.num_face, T, "fp32", tok_engine)
+        except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the bench line
+            out["config3_shard_exact_fp32"] = {"error": repr(e)[:200]}
+        log("configs[3] shard, exact mode, done")
         # secondary figure (not `value`): the same workload in the fp16-storage fast mode, the reference's GPU dtype
         del lmm
         torch.cuda.empty_cache()
@@ -533,19 +602,20 @@ def main(argv=None):
                                 "us_per_token": round(v["avg_us"] * LAUNCHES_PER_TOKEN[k], 2)} for k, v in fprof.items()}})
         except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the bench line
             out["fast_mode_fp16"]["kernels_error"] = repr(e)[:200]
-        # and the batched shard of BASELINE configs[3] (32 independent clouds per GPU), short run: aggregate decode rate
+        # the batched shard of BASELINE configs[3] (32 independent clouds per GPU) at FULL size in the fast mode, and how far its greedy
+        # streams follow the exact mode's on the same clouds (how bit-exact the mode is that configs[3] is quoted in)
         try:
-            Bx, Tx = 32, 256
-            pcs = torch.cat([W.synthetic_point_cloud(i, args.points) for i in range(Bx)]).to(dev)
-            fast.generate(pcs, args.num_face, tokenizer=object(), max_new_tokens=Tx, min_new_tokens=Tx)
-            bms = fast.mesh_decoder.last_decode_ms
-            bb = W_ELEMS * 2 + Bx * KV_ELEMS_PER_POS * (2050 + (Tx - 1) / 2.0 + 1) * 2
-            out["batch32_fp16"] = {"aggregate_decode_tokens_per_s": round(Bx * Tx / bms * 1e3, 1), "tokens_per_row": Tx,
-                                   "hbm_frac": round(bb / (bms / Tx * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "note": "32 clouds in one batch on one GPU (matrix-core projections, weights streamed "
-                                           "once per step), context 2050..2306; full-length figures in DESIGN.md section 6"}
+            out["config3_shard_fp16"], fast_toks = config3_shard_extra(fast, dev, args.points, args.num_face, T, "fp16", tok_engine)
+            if exact_toks is not None:
+                fd = first_divergence(fast_toks, exact_toks)
+                out["config3_shard_fp16"]["greedy_ids_vs_exact_fp32"] = {
+                    "first_divergence_index_per_row": {"min": int(min(fd)), "median": int(np.median(fd)), "max": int(max(fd))},
+                    "rows_identical_over_T": int(sum(1 for v in fd if v >= T)), "rows": len(fd),
+                    "note": "index of the first greedy id that differs from the exact-fp32 run of the same cloud (T = never): fp16 storage "
+                            "moves logits by ~1e-3, a near-tie flips an arg-max and the streams separate from there"}
         except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the bench line
-            out["batch32_fp16"] = {"error": repr(e)[:200]}
+            out["config3_shard_fp16"] = {"error": repr(e)[:200]}
+        log("configs[3] shard, fast mode, done")
         # BASELINE configs[2]'s shape (B = 32, SAMPLE mode top-k 10, test_num_face = 4000, fp16) at a reduced length: the
         # full T = 16000 run takes 143 s (profiles/r02_config3_B32_T16000_fp16_sample.log: 3.58k tok/s = 68 % of 8 TB/s)
         try:
@@ -566,7 +636,7 @@ def main(argv=None):
         except Exception as e:  # noqa: BLE001
             out["config2_shape_sample_fp16"] = {"error": repr(e)[:200]}
         del fast
-        log("fast-mode + batch-32 passes done")
+        log("fast-mode + configs[2]-shape passes done")
         try:
             torch.cuda.empty_cache()
             out["dit_front_end_fp16"] = dit_front_end_extra(dev)

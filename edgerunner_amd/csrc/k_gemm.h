@@ -495,8 +495,21 @@ __host__ __device__ inline int gemm_hh_geglu_row(int p, int F) {
     return blk == 0 ? j : F + j;
 }
 
+// Operands of the plain row-wise epilogue a caller already holds in registers (k_gemm_stream.h requests them when a tile STARTS, so
+// they arrive under the k-loop): bias at the lane's four columns, the gate rows of the two batches the wave's rows can lie in, the
+// residual float4 of every pass.  Loaded with exactly the lane map and the `vec` condition of gemm_hh_epilogue (hh_epi_vec).
+struct HhEpiPre {
+    f32x4 bias, gate0, gate1;
+    int gb0, gb1;
+    f32x4 res[8];          // WR / RPP passes of a (32 TM) x (32 TN) block with TM = 1, TN = 2
+};
+__device__ __forceinline__ bool hh_epi_vec(const GemmArgs& g, int gn) {
+    return gn + 3 < g.N && (!g.C || !(g.ldc & 3)) && (!g.resid || !(g.ldr & 3)) && !(g.gate_bstride & 3) && (!g.c16 || !(g.ldc16 & 3));
+}
+
 template <int TM, int TN, int HEPI>
-__device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+__device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane,
+                                                 const HhEpiPre* pre = nullptr) {
     constexpr int WR = 32 * TM, WC = 32 * TN;
     static_assert(HEPI == HEPI_PLAIN || TN == 2, "GEGLU pairs the wave's two 32-column blocks");
     const int kh = lane >> 5, li = lane & 31;
@@ -541,40 +554,71 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
         const int c4 = lane % LPR, rr0 = lane / LPR;
         const int gn = nw + 4 * c4;
         if (gn >= g.N) return;
-        const bool vec = gn + 3 < g.N && (!g.C || !(g.ldc & 3)) && (!g.resid || !(g.ldr & 3)) && !(g.gate_bstride & 3) && (!g.c16 || !(g.ldc16 & 3));
+        const bool vec = hh_epi_vec(g, gn);
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) {
+        if (pre) bias = pre->bias;
+        else if (g.bias) {
             bias.x = g.bias[gn];
             if (gn + 1 < g.N) bias.y = g.bias[gn + 1];
             if (gn + 2 < g.N) bias.z = g.bias[gn + 2];
             if (gn + 3 < g.N) bias.w = g.bias[gn + 3];
         }
         const RowBatch gb(mw, g.gate ? g.gate_rows : 0, WR), rb(mw, (g.resid && g.resid_mod > 0) ? g.resid_mod : 0, WR);
-#pragma unroll 4
-        for (int t = 0; t < WR / RPP; ++t) {
-            const int rr = rr0 + RPP * t, gm = mw + rr;
-            if (gm >= g.M) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c4);
-            if (g.div != 0.f) { v.x = v.x / g.div; v.y = v.y / g.div; v.z = v.z / g.div; v.w = v.w / g.div; }
-            v += bias;
-            if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            const long long rrow = g.resid ? (long long)(g.resid_mod > 0 ? rb.inner(gm) : gm) * g.ldr + gn : 0;
-            const long long grow = g.gate ? (long long)gb.batch(gm) * g.gate_bstride + gn : 0;
-            if (vec) {
-                if (g.gate) v *= *reinterpret_cast<const f32x4*>(g.gate + grow);
-                if (g.resid) v += *reinterpret_cast<const f32x4*>(g.resid + rrow);
-                if (g.C) *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;     // null: only the fp16 copy is wanted
-                if (g.c16) *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * g.ldc16 + gn) = (h16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-            } else {
-                const float e[4] = {v.x, v.y, v.z, v.w};
+        // The residual and gate operands of EIGHT passes are requested before the first of them is used (round 6): with the loads inside
+        // a 4-fold unrolled pass loop a wave had 4 x 1 KB in flight, 16-32 KB per CU - at ~2 us of loaded latency that is 2-4 TB/s, and
+        // the epilogue of a 4096 x 1024 residual product (42 MB) took 10 of the launch's 22 us (profiles/r06_gemm_stream_probe_v3.log).
+        // The gate row depends on the batch only: the wave's rows span at most two batches (RowBatch fast path), one float4 each.
+        constexpr int NPASS = WR / RPP, CH = NPASS < 8 ? NPASS : 8;
+        f32x4 gate0 = {1.f, 1.f, 1.f, 1.f}, gate1 = gate0;
+        int gb0 = 0, gb1 = 0;
+        if (pre) { gate0 = pre->gate0; gate1 = pre->gate1; gb0 = pre->gb0; gb1 = pre->gb1; }
+        else if (g.gate && vec) {
+            gb0 = gb.batch(mw);
+            gb1 = gb.batch(min(mw + WR - 1, g.M - 1));
+            gate0 = *reinterpret_cast<const f32x4*>(g.gate + (long long)gb0 * g.gate_bstride + gn);
+            gate1 = *reinterpret_cast<const f32x4*>(g.gate + (long long)gb1 * g.gate_bstride + gn);
+        }
+        const bool gate_pair = g.gate && vec && gb.fast;       // every row of the wave is in batch gb0 or gb1
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (gn + u >= g.N) break;
-                    float w = e[u];
-                    if (g.gate) w *= g.gate[grow + u];
-                    if (g.resid) w += g.resid[rrow + u];
-                    if (g.C) g.C[(long long)gm * g.ldc + gn + u] = w;
-                    if (g.c16) g.c16[(long long)gm * g.ldc16 + gn + u] = (_Float16)w;
+        for (int c0 = 0; c0 < NPASS; c0 += CH) {
+            f32x4 rres[CH];
+            if (NPASS <= 8 && pre) {                       // (HhEpiPre holds the eight passes of a 32-row block: TM = 1 callers only)
+#pragma unroll
+                for (int t = 0; t < CH; ++t) rres[t] = pre->res[(c0 + t) & 7];
+            } else if (g.resid && vec) {
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int gm = mw + rr0 + RPP * (c0 + t);
+                    const int rrow_ = g.resid_mod > 0 ? rb.inner(min(gm, g.M - 1)) : min(gm, g.M - 1);
+                    rres[t] = *reinterpret_cast<const f32x4*>(g.resid + (long long)rrow_ * g.ldr + gn);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int rr = rr0 + RPP * (c0 + t), gm = mw + rr;
+                if (gm >= g.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c4);
+                if (g.div != 0.f) { v.x = v.x / g.div; v.y = v.y / g.div; v.z = v.z / g.div; v.w = v.w / g.div; }
+                v += bias;
+                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                const long long rrow = g.resid ? (long long)(g.resid_mod > 0 ? rb.inner(gm) : gm) * g.ldr + gn : 0;
+                const long long grow = g.gate ? (long long)gb.batch(gm) * g.gate_bstride + gn : 0;
+                if (vec) {
+                    if (g.gate) v *= gate_pair ? (gb.batch(gm) == gb0 ? gate0 : gate1) : *reinterpret_cast<const f32x4*>(g.gate + grow);
+                    if (g.resid) v += rres[t];
+                    if (g.C) *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;     // null: only the fp16 copy is wanted
+                    if (g.c16) *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * g.ldc16 + gn) = (h16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (gn + u >= g.N) break;
+                        float w = e[u];
+                        if (g.gate) w *= g.gate[grow + u];
+                        if (g.resid) w += g.resid[rrow + u];
+                        if (g.C) g.C[(long long)gm * g.ldc + gn + u] = w;
+                        if (g.c16) g.c16[(long long)gm * g.ldc16 + gn + u] = (_Float16)w;
+                    }
                 }
             }
         }

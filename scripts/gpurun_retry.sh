@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build-container helper: gpurun with retries while every GPU slot of the pod is busy (exit code 3 = nothing charged).
+# usage: scripts/gpurun_retry.sh <timeout_s> '<remote command>'
+T=$1; shift
+for i in $(seq 1 30); do
+  /usr/local/graft/bin/gpurun --timeout "$T" -- "$@"; rc=$?
+  [ $rc -ne 3 ] && exit $rc
+  sleep 45
+done
+exit 3
