@@ -497,40 +497,46 @@ __host__ __device__ inline int gemm_hh_geglu_row(int p, int F) {
 
 // Operands of the plain row-wise epilogue a caller already holds in registers (k_gemm_stream.h requests them when a tile STARTS, so
 // they arrive under the k-loop): bias at the lane's four columns, the gate rows of the two batches the wave's rows can lie in, the
-// residual float4 of every pass.  Loaded with exactly the lane map and the `vec` condition of gemm_hh_epilogue (hh_epi_vec).
+// residual float4 of every pass of the call.  Loaded with exactly the lane map and the `vec` condition of hh_epi_rows (hh_epi_vec).
 struct HhEpiPre {
     f32x4 bias, gate0, gate1;
     int gb0, gb1;
-    f32x4 res[8];          // WR / RPP passes of a (32 TM) x (32 TN) block with TM = 1, TN = 2
+    f32x4 res[8];          // res[t]: the t-th row pass the call handles (at most eight)
 };
 __device__ __forceinline__ bool hh_epi_vec(const GemmArgs& g, int gn) {
     return gn + 3 < g.N && (!g.C || !(g.ldc & 3)) && (!g.resid || !(g.ldr & 3)) && !(g.gate_bstride & 3) && (!g.c16 || !(g.ldc16 & 3));
 }
 
-template <int TM, int TN, int HEPI>
-__device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane,
-                                                 const HhEpiPre* pre = nullptr) {
-    constexpr int WR = 32 * TM, WC = 32 * TN;
-    static_assert(HEPI == HEPI_PLAIN || TN == 2, "GEGLU pairs the wave's two 32-column blocks");
+// accumulators -> the wave's (32 TM) x (32 TN) float slice of LDS, row-major
+template <int TM, int TN>
+__device__ __forceinline__ void hh_epi_stage(float* sw, const f32x16 (&acc)[TM][TN], int lane) {
+    constexpr int WC = 32 * TN;
     const int kh = lane >> 5, li = lane & 31;
-#ifdef ER_GEMM_PROBE_NO_EPILOGUE
-    if (acc[0][0][0] != 12345.678f) return;
-#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sw[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh) * WC + 32 * j + li] = acc[i][j][r];
-    // (same wave writes and reads: the LDS queue is in order, no barrier)
+}
+
+// the row-wise part: LDS slice -> bias / gate / residual / stores.  PARTS = 2: this call handles half `part` (0 / 1) of the slice's row
+// passes (keys for the V^T form) - the streamed kernel's loader waves take the second half of every matrix wave's block.
+// `pre_` + use_pre (optional): the operands of THIS call's passes, already in registers (res[t] = the t-th pass of this part); the flag
+// is separate from the pointer so that the struct stays in registers (a pointer that may be null at run time sends it to scratch).
+template <int TM, int TN, int HEPI, int PARTS = 1>
+__device__ __forceinline__ void hh_epi_rows(const GemmArgs& g, const float* sw, int mw, int nw, int lane, int part = 0, const HhEpiPre* pre_ = nullptr,
+                                            bool use_pre = false) {
+    constexpr int WR = 32 * TM, WC = 32 * TN;
+    static_assert(HEPI == HEPI_PLAIN || TN == 2, "GEGLU pairs the wave's two 32-column blocks");
     if constexpr (HEPI == HEPI_PLAIN) {
         if (nw >= g.N) return;                // a wave whose whole column block lies beyond N (256-wide tiles on N % 256 != 0)
         if (g.vt16 && nw >= g.vt_col0) {      // wave-uniform: the V columns of this wave's block go out as V^T rows
             // lane -> (column d of the block, a run of WR / LPD keys): 16 keys per step = two 16-byte chunks of the V^T row in
             // fa_vt_pos order ({0-3, 8-11}, {4-7, 12-15}); the column walk down the LDS rows is conflict-free up to the two lanes
             // that share a bank when the block is 64 columns wide
-            constexpr int LPD = 64 / WC, KPL = WR / LPD;
-            static_assert(KPL % 16 == 0, "whole 16-key groups per lane");
+            constexpr int LPD = 64 / WC, KPL = WR / LPD, NQ = KPL / 16;
+            static_assert(KPL % 16 == 0 && NQ % PARTS == 0, "whole 16-key groups per lane and part");
             const int d = lane % WC, kk0 = (lane / WC) * KPL;
             const int col = nw - g.vt_col0 + d, hh = col >> 6, dd = col & 63;
             const int heads = (g.N - g.vt_col0) >> 6;
@@ -539,7 +545,8 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
             if (gm0 >= g.M) return;
             _Float16* dst = g.vt16 + (((long long)b * heads + hh) * 64 + dd) * g.vt_ld + key0;
 #pragma unroll
-            for (int q = 0; q < KPL / 16; ++q) {
+            for (int q_ = 0; q_ < NQ / PARTS; ++q_) {
+                const int q = q_ + part * (NQ / PARTS);
                 float e[16];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) e[t] = sw[(kk0 + 16 * q + t) * WC + d] + bias;
@@ -556,7 +563,7 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
         if (gn >= g.N) return;
         const bool vec = hh_epi_vec(g, gn);
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (pre) bias = pre->bias;
+        if (use_pre) bias = pre_->bias;
         else if (g.bias) {
             bias.x = g.bias[gn];
             if (gn + 1 < g.N) bias.y = g.bias[gn + 1];
@@ -564,14 +571,15 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
             if (gn + 3 < g.N) bias.w = g.bias[gn + 3];
         }
         const RowBatch gb(mw, g.gate ? g.gate_rows : 0, WR), rb(mw, (g.resid && g.resid_mod > 0) ? g.resid_mod : 0, WR);
-        // The residual and gate operands of EIGHT passes are requested before the first of them is used (round 6): with the loads inside
-        // a 4-fold unrolled pass loop a wave had 4 x 1 KB in flight, 16-32 KB per CU - at ~2 us of loaded latency that is 2-4 TB/s, and
-        // the epilogue of a 4096 x 1024 residual product (42 MB) took 10 of the launch's 22 us (profiles/r06_gemm_stream_probe_v3.log).
+        // The residual and gate operands of up to EIGHT passes are requested before the first of them is used (round 6): with the loads
+        // inside a 4-fold unrolled pass loop a wave had 4 x 1 KB in flight, 16-32 KB per CU - at ~2 us of loaded latency that is 2-4 TB/s.
         // The gate row depends on the batch only: the wave's rows span at most two batches (RowBatch fast path), one float4 each.
-        constexpr int NPASS = WR / RPP, CH = NPASS < 8 ? NPASS : 8;
+        constexpr int NPASS = WR / RPP / PARTS, CH = NPASS < 8 ? NPASS : 8;
+        static_assert((WR / RPP) % PARTS == 0, "whole passes per part");
+        const int t0 = part * NPASS;
         f32x4 gate0 = {1.f, 1.f, 1.f, 1.f}, gate1 = gate0;
         int gb0 = 0, gb1 = 0;
-        if (pre) { gate0 = pre->gate0; gate1 = pre->gate1; gb0 = pre->gb0; gb1 = pre->gb1; }
+        if (use_pre) { gate0 = pre_->gate0; gate1 = pre_->gate1; gb0 = pre_->gb0; gb1 = pre_->gb1; }
         else if (g.gate && vec) {
             gb0 = gb.batch(mw);
             gb1 = gb.batch(min(mw + WR - 1, g.M - 1));
@@ -582,20 +590,20 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
 #pragma unroll
         for (int c0 = 0; c0 < NPASS; c0 += CH) {
             f32x4 rres[CH];
-            if (NPASS <= 8 && pre) {                       // (HhEpiPre holds the eight passes of a 32-row block: TM = 1 callers only)
+            if (NPASS <= 8 && use_pre) {                       // (HhEpiPre holds at most eight passes: 32-row blocks only)
 #pragma unroll
-                for (int t = 0; t < CH; ++t) rres[t] = pre->res[(c0 + t) & 7];
+                for (int t = 0; t < CH; ++t) rres[t] = pre_->res[(c0 + t) & 7];
             } else if (g.resid && vec) {
 #pragma unroll
                 for (int t = 0; t < CH; ++t) {
-                    const int gm = mw + rr0 + RPP * (c0 + t);
+                    const int gm = mw + rr0 + RPP * (t0 + c0 + t);
                     const int rrow_ = g.resid_mod > 0 ? rb.inner(min(gm, g.M - 1)) : min(gm, g.M - 1);
                     rres[t] = *reinterpret_cast<const f32x4*>(g.resid + (long long)rrow_ * g.ldr + gn);
                 }
             }
 #pragma unroll
             for (int t = 0; t < CH; ++t) {
-                const int rr = rr0 + RPP * (c0 + t), gm = mw + rr;
+                const int rr = rr0 + RPP * (t0 + c0 + t), gm = mw + rr;
                 if (gm >= g.M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c4);
                 if (g.div != 0.f) { v.x = v.x / g.div; v.y = v.y / g.div; v.z = v.z / g.div; v.w = v.w / g.div; }
@@ -624,14 +632,15 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
         }
     } else {
         // GEGLU: lane -> (row, 4 outputs): value part at columns 4 c .. +3, gate part at 32 + 4 c .. +3 of the wave's block
-        constexpr int LPR = 8, RPP = 8;
+        constexpr int LPR = 8, RPP = 8, NPASS = WR / RPP / PARTS;
+        static_assert((WR / RPP) % PARTS == 0, "whole passes per part");
         const int c = lane % LPR, rr0 = lane / LPR;
         const int F = g.N >> 1;                                   // outputs per row
         const int jo = (nw >> 1) + 4 * c;                         // output column: permuted column nw + l <-> output nw / 2 + l
         const f32x4 bx = *reinterpret_cast<const f32x4*>(g.bias + nw + 4 * c), bg = *reinterpret_cast<const f32x4*>(g.bias + nw + 32 + 4 * c);
 #pragma unroll 4
-        for (int t = 0; t < WR / RPP; ++t) {
-            const int rr = rr0 + RPP * t, gm = mw + rr;
+        for (int t_ = 0; t_ < NPASS; ++t_) {
+            const int rr = rr0 + RPP * (t_ + part * NPASS), gm = mw + rr;
             if (gm >= g.M) continue;
             f32x4 x = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c);
             f32x4 gt = *reinterpret_cast<const f32x4*>(sw + rr * WC + 32 + 4 * c);
@@ -644,6 +653,16 @@ __device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, c
             *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * F + jo) = (h16x4){(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
         }
     }
+}
+
+template <int TM, int TN, int HEPI>
+__device__ __forceinline__ void gemm_hh_epilogue(const GemmArgs& g, float* sw, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+#ifdef ER_GEMM_PROBE_NO_EPILOGUE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    hh_epi_stage<TM, TN>(sw, acc, lane);
+    // (same wave writes and reads: the LDS queue is in order, no barrier)
+    hh_epi_rows<TM, TN, HEPI>(g, sw, mw, nw, lane);
 }
 
 // SPLIT: the A operand is hi + lo (two fp16 arrays: a = fp16(x), lo = fp16(x - hi), |x - hi - lo| <= 2^-22 |x|), every weight fragment

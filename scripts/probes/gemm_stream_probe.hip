@@ -1,13 +1,13 @@
 // Round 6: the streamed LDS-DMA GEMM (k_gemm_stream.h, loader + matrix waves, five-stage ring, persistent tile stream) against the
 // 4-wave and 256 x 256 kernels of k_gemm.h on the DiT shapes: throughput AND bit-equality of every epilogue form
 // (plain with bias / gate / residual / fp16 copy, V^T of a fused q/k/v projection, GEGLU), ragged shapes included.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I ../../edgerunner_amd/csrc -o gemm_stream_probe gemm_stream_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I ../../edgerunner_amd/csrc -I . -o gemm_stream_probe gemm_stream_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "k_gemm_stream.h"
+#include "k_gemm_stream.h"   // scripts/probes/k_gemm_stream.h (probe-only kernel)
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 using namespace er;
 

@@ -16,11 +16,14 @@
 //   * the k-tiles of ALL the output tiles a workgroup owns form one stream (persistent grid, one workgroup per CU): while the matrix
 //     waves run a tile's epilogue the ring fills with the next tile's first k-tiles, so only the first tile of a launch pays the
 //     first-byte latency;
-//   * the epilogue is k_gemm.h's row-wise one (gemm_hh_epilogue: transposed through LDS, 16 bytes per lane, 256 contiguous bytes per
-//     16 lanes; V^T and GEGLU forms included), run twice per wave on 32 x 64 halves through the ONE ring stage that is free after a
-//     tile's last k-step; the loaders hold the refill of that stage back behind one extra barrier per output tile.  (A first version
-//     accumulated the product transposed and stored straight from the accumulator registers - 32-byte row segments per lane pair: its
-//     epilogue cost 16 us against 10 us on the 4096 x 1024 residual shape, profiles/r06_gemm_stream_probe_v2.log.)
+//   * the epilogue is k_gemm.h's row-wise one (hh_epi_stage / hh_epi_rows: transposed through LDS, 16 bytes per lane, 256 contiguous
+//     bytes per 16 lanes; V^T and GEGLU forms included) on ALL EIGHT waves: a matrix wave stages a 32 x 64 half of its block into the
+//     ONE ring stage that is free after a tile's last k-step, then it and its loader wave finish half of the row passes each; the
+//     refill of that stage waits for the epilogue's last barrier.  Plain form: bias / gate / residual of a wave's passes are requested a
+//     k-loop (matrix waves) or a k-step (loaders) ahead.  (A first version accumulated the product transposed and stored straight from
+//     the accumulator registers - 32-byte row segments per lane pair: 16 us against 10 us on the 4096 x 1024 residual shape,
+//     profiles/r06_gemm_stream_probe_v2.log; a second ran the row-wise epilogue on the four matrix waves only: 11-14 k cycles per tile,
+//     r06_gemm_stream_probe_v6.log.)
 // Same 128-byte row images, XOR swizzle, fragment reads and the same k order per accumulator element as gemm_hh_mfma_kernel; a product
 // a.w is the same number whichever operand slot it enters by: results are BIT-IDENTICAL to the 4-wave kernels (tests/test_gpu_kernels.py).
 #pragma once
@@ -53,6 +56,34 @@ __device__ __forceinline__ void gs_wait_tiles(int n) {      // at most n (<= NT)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Operands of one wave's share of a tile's epilogue (plain form), requested ahead of use: half h = rows 32 h .. 32 h + 31 of the 64 x 64
+// block at (mwb, nwb); part 0 (the matrix wave that owns the block) takes row passes 0..3 of a half, part 1 (its loader wave) 4..7.
+__device__ __forceinline__ void gs_load_pre(const GemmArgs& g, HhEpiPre (&pre)[2], int mwb, int nwb, int lane, int part) {
+    const int gn = nwb + 4 * (lane & 15), rr0 = lane >> 4;
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + gn) : zero;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m0h = mwb + 32 * h;
+        pre[h].bias = bias;
+        pre[h].gate0 = pre[h].gate1 = one;
+        pre[h].gb0 = pre[h].gb1 = 0;
+        if (g.gate) {
+            pre[h].gb0 = min(m0h, g.M - 1) / g.gate_rows;
+            pre[h].gb1 = min(m0h + 31, g.M - 1) / g.gate_rows;
+            pre[h].gate0 = *reinterpret_cast<const f32x4*>(g.gate + (long long)pre[h].gb0 * g.gate_bstride + gn);
+            pre[h].gate1 = *reinterpret_cast<const f32x4*>(g.gate + (long long)pre[h].gb1 * g.gate_bstride + gn);
+        }
+        if (g.resid) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int gm = min(m0h + rr0 + 4 * (t + 4 * part), g.M - 1);
+                pre[h].res[t] = *reinterpret_cast<const f32x4*>(g.resid + (long long)(g.resid_mod > 0 ? gm % g.resid_mod : gm) * g.ldr + gn);
+            }
+        }
+    }
+}
+
 template <int S, int HEPI>
 __global__ __launch_bounds__(GS_THREADS) void gemm_hh_stream_kernel(GemmArgs g, int ntx, int ntiles) {
     static_assert(S >= 3 && S <= 5, "ring depth");
@@ -70,6 +101,20 @@ __global__ __launch_bounds__(GS_THREADS) void gemm_hh_stream_kernel(GemmArgs g, 
     const int mine = slot < nx ? (nx - slot + wx - 1) / wx : 0;                    // tiles base + slot + j wx, j < mine
     const int total = mine * nk;                                                   // k-tiles in this workgroup's stream
     if (total == 0) return;
+    // EPILOGUE of a tile, all eight waves: the 64 x 64 block of matrix wave b goes through LDS in two halves of 32 rows - b stages a
+    // half into its 8 KB of the ring stage the tile's last k-tile left, a barrier, then b finishes row passes 0..3 and loader wave b + 4
+    // passes 4..7 (hh_epi_rows, PARTS = 2), every wave's reads of the stage returned, a barrier.  Four epilogue waves per CU took 11 us
+    // for the stores of a 4096 x 1024 residual tile set (profiles/r06_gemm_stream_probe_v6.log); the loaders are idle anyway:
+    // the refill of that stage has to wait for the epilogue's last barrier.
+    const int eb = wid & 3, epart = wid >> 2;
+    auto epilogue_rows = [&](int stage, int h, int mwb, int nwb, const HhEpiPre& pre, bool use_pre) {
+        const float* sw = reinterpret_cast<const float*>(lds + stage * GS_STAGE_B) + eb * (32 * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // the half is staged (the stager's ds_writes have completed)
+#ifndef ER_GEMM_PROBE_NO_EPILOGUE
+        hh_epi_rows<1, 2, HEPI, 2>(g, sw, mwb + 32 * h, nwb, lane, epart, &pre, use_pre);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // everybody's reads of the stage have returned
+    };
 
     if (wid >= 4) {
         // ---------------- loader waves: pieces lw * 4 + jj of the A image and of the B image of every k-tile ----------------
@@ -92,7 +137,7 @@ __global__ __launch_bounds__(GS_THREADS) void gemm_hh_stream_kernel(GemmArgs g, 
                 vb[jj] = (unsigned)min(tx * GS_BN + r, g.N - 1) * (unsigned)(g.ldb * 2) + sw + 3072u - 1024u * jj;
             }
         };
-        int jt = 0, kt = 0, cur = 0;
+        int ji = 0, kt = 0, cur = 0;                                                // the next k-tile to issue: tile index, k index, ring stage
         set_tile(0);
         auto issue_next = [&]() {
             const unsigned sa = lds0 + (unsigned)cur * GS_STAGE_B + (unsigned)lw * 4096u, sb = sa + GS_BM * XBK * 2;
@@ -109,7 +154,7 @@ __global__ __launch_bounds__(GS_THREADS) void gemm_hh_stream_kernel(GemmArgs g, 
                          : "=&s"(keep) : "v"(vb[0]), "v"(vb[1]), "v"(vb[2]), "v"(vb[3]), "s"(sb), "s"(gb) : "memory");
             if (++kt == nk) {
                 kt = 0;
-                if (++jt < mine) set_tile(jt);
+                if (++ji < mine) set_tile(ji);
             }
             cur = cur + 1 == S ? 0 : cur + 1;
         };
@@ -120,30 +165,41 @@ __global__ __launch_bounds__(GS_THREADS) void gemm_hh_stream_kernel(GemmArgs g, 
 #ifdef GS_TIMELINE
         unsigned long long t_issue = 0, t_wait = 0, t_bar = 0;
 #endif
-        int next_tile_at = nk;
-        for (int u = 0; u < total; ++u) {
-            // first k-step of a further output tile: the matrix waves run the previous tile's epilogue through the stage k-tile u - 1 left;
-            // its refill waits for their barrier behind the epilogue
-            if (u == next_tile_at) {
+        int u = 0, est = 0;                                                         // est: ring stage of k-tile u
+        for (int jt = 0; jt < mine; ++jt) {
+            int ty, tx;
+            gs_tile_coords(base + slot + jt * wx, ntx, nty, ty, tx);
+            const int mwb = ty * GS_BM + (lw >> 1) * 64, nwb = tx * GS_BN + (lw & 1) * 64;     // the block of matrix wave lw
+            HhEpiPre pre[2];
+            bool use_pre = false;
+            for (int t = 0; t < nk; ++t, ++u) {
+#ifdef GS_TIMELINE
+                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
+                if (issued < total) { issue_next(); ++issued; }                     // k-tile u + S - 1 into the stage k-tile u - 1 left
+#ifdef GS_TIMELINE
+                const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
+                if constexpr (HEPI == HEPI_PLAIN) {
+                    if (t == nk - 1) {                                              // this wave's epilogue operands, one k-step ahead of their use
+                        use_pre = hh_epi_vec(g, nwb + 60) && !(g.vt16 && nwb >= g.vt_col0);
+                        if (use_pre) gs_load_pre(g, pre, mwb, nwb, lane, 1);
+                    }
+                }
+                gs_wait_tiles<S - 3>(issued - 3 - u);                               // k-tile u + 2 has landed
+#ifdef GS_TIMELINE
+                const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+#endif
                 asm volatile("s_barrier" ::: "memory");
-                next_tile_at += nk;
+#ifdef GS_TIMELINE
+                const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+                t_issue += c1 - c0; t_wait += c2 - c1; t_bar += c3 - c2;
+#endif
+                est = est + 1 == S ? 0 : est + 1;
             }
-#ifdef GS_TIMELINE
-            const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-#endif
-            if (issued < total) { issue_next(); ++issued; }                         // k-tile u + S - 1 into the stage k-tile u - 1 left
-#ifdef GS_TIMELINE
-            const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-#endif
-            gs_wait_tiles<S - 3>(issued - 3 - u);                                   // k-tile u + 2 has landed
-#ifdef GS_TIMELINE
-            const unsigned long long c2 = __builtin_amdgcn_s_memtime();
-#endif
-            asm volatile("s_barrier" ::: "memory");
-#ifdef GS_TIMELINE
-            const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-            t_issue += c1 - c0; t_wait += c2 - c1; t_bar += c3 - c2;
-#endif
+            const int free_stage = est == 0 ? S - 1 : est - 1;                      // the stage the tile's last k-tile left
+            epilogue_rows(free_stage, 0, mwb, nwb, pre[0], use_pre);
+            epilogue_rows(free_stage, 1, mwb, nwb, pre[1], use_pre);
         }
 #ifdef GS_TIMELINE
         if (wid == 4 && lane == 0) {
@@ -187,110 +243,77 @@ __global__ __launch_bounds__(GS_THREADS) void gemm_hh_stream_kernel(GemmArgs g, 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // plain epilogue: its global operands (bias, the two possible gate rows, the residual of all 2 x 8 row passes) are requested NOW
-        // and arrive under the k-loop - with four epilogue waves per CU their latency was the epilogue (13 us of a 24 us launch on the
-        // 4096 x 1024 residual shape, profiles/r06_gemm_stream_probe_v5.log).  Lane map and conditions of gemm_hh_epilogue<1, 2>.
+        // plain epilogue: this wave's global operands (bias, the two possible gate rows, the residual of its 2 x 4 row passes) are requested
+        // NOW and arrive under the k-loop.  Wave-uniform condition: the wave's 64 columns lie inside N and every row-wise access is a
+        // 16-byte one (else hh_epi_rows loads by itself); lane map and conditions of hh_epi_rows<1, 2>.
         HhEpiPre pre[2];
         bool use_pre = false;
         if constexpr (HEPI == HEPI_PLAIN) {
-            const int gn = nw + 4 * (lane & 15), rr0 = lane >> 4;
-            // wave-uniform: the wave's 64 columns lie inside N and every row-wise access is a 16-byte one (else: the epilogue loads by itself)
             use_pre = hh_epi_vec(g, nw + 60) && !(g.vt16 && nw >= g.vt_col0);
-            if (use_pre) {
-                const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 bias = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + gn) : zero;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int m0h = mw + 32 * h;
-                    pre[h].bias = bias;
-                    pre[h].gate0 = pre[h].gate1 = one;
-                    pre[h].gb0 = pre[h].gb1 = 0;
-                    if (g.gate) {
-                        pre[h].gb0 = min(m0h, g.M - 1) / g.gate_rows;
-                        pre[h].gb1 = min(m0h + 31, g.M - 1) / g.gate_rows;
-                        pre[h].gate0 = *reinterpret_cast<const f32x4*>(g.gate + (long long)pre[h].gb0 * g.gate_bstride + gn);
-                        pre[h].gate1 = *reinterpret_cast<const f32x4*>(g.gate + (long long)pre[h].gb1 * g.gate_bstride + gn);
-                    }
-                    if (g.resid) {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const int gm = min(m0h + rr0 + 4 * t, g.M - 1);
-                            pre[h].res[t] = *reinterpret_cast<const f32x4*>(g.resid + (long long)(g.resid_mod > 0 ? gm % g.resid_mod : gm) * g.ldr + gn);
-                        }
-                    }
-                }
-            }
+            if (use_pre) gs_load_pre(g, pre, mw, nw, lane, 0);
         }
-        {
-            for (int t = 0; t < nk; ++t, ++u) {
+        for (int t = 0; t < nk; ++t, ++u) {
 #ifdef GS_TIMELINE
-                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+            const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
-                const int nxt = cur + 1 == S ? 0 : cur + 1;
+            const int nxt = cur + 1 == S ? 0 : cur + 1;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    // fragments two sub-steps ahead: k-tile u + 1 was certified by barrier u - 1.  UNCONDITIONAL - behind the stream's last
-                    // k-tile the two sets are read from a stage nobody fills and never used: a branch here makes hipcc wait for every
-                    // outstanding ds_read at the join (lgkmcnt(1) / (0) in front of sub-step 3's MFMAs instead of lgkmcnt(8))
+            for (int ks = 0; ks < 4; ++ks) {
+                // fragments two sub-steps ahead: k-tile u + 1 was certified by barrier u - 1.  UNCONDITIONAL - behind the stream's last
+                // k-tile the two sets are read from a stage nobody fills and never used: a branch here makes hipcc wait for every
+                // outstanding ds_read at the join (lgkmcnt(1) / (0) in front of sub-step 3's MFMAs instead of lgkmcnt(8))
 #ifndef GS_ABL_NOREAD
-                    if (ks == 0) GS_FRAGS(cur, 2, 2);
-                    if (ks == 1) GS_FRAGS(cur, 3, 3);
-                    if (ks == 2) GS_FRAGS(nxt, 0, 0);
-                    if (ks == 3) GS_FRAGS(nxt, 1, 1);
+                if (ks == 0) GS_FRAGS(cur, 2, 2);
+                if (ks == 1) GS_FRAGS(cur, 3, 3);
+                if (ks == 2) GS_FRAGS(nxt, 0, 0);
+                if (ks == 3) GS_FRAGS(nxt, 1, 1);
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
 #ifdef GS_ABL_NOMFMA
-                    if (ks == 0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[0][0] + bv[1][1] + bv[2][0] + bv[3][1], av[0][0] + av[1][1] + av[2][0] + av[3][1], acc[0][0], 0, 0, 0);
-                    if (ks < 0)
+                if (ks == 0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv[0][0] + bv[1][1] + bv[2][0] + bv[3][1], av[0][0] + av[1][1] + av[2][0] + av[3][1], acc[0][0], 0, 0, 0);
+                if (ks < 0)
 #endif
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#ifdef GS_TIMELINE
-                asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));     // the MFMAs have retired
-                const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-#endif
-                asm volatile("s_barrier" ::: "memory");                             // k-tile u's stage is free; k-tile u + 2 is in LDS
-#ifdef GS_TIMELINE
-                const unsigned long long c2 = __builtin_amdgcn_s_memtime();
-                tl_work += c1 - c0; tl_bar += c2 - c1;
-#endif
-                cur = nxt;
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef GS_TIMELINE
+            asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));     // the MFMAs have retired
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
+            asm volatile("s_barrier" ::: "memory");                                 // k-tile u's stage is free; k-tile u + 2 is in LDS
+#ifdef GS_TIMELINE
+            const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+            tl_work += c1 - c0; tl_bar += c2 - c1;
+#endif
+            cur = nxt;
         }
-#ifdef ER_GEMM_PROBE_NO_EPILOGUE      // scripts/probes/gemm_stream_probe.hip: what the k-loop costs without the epilogue
-        if (acc[0][0][0] == 12345.678f && acc[1][1][5] == 3.f && acc[0][1][7] == 1.f && acc[1][0][2] == 9.f) g.C[lane] = 1.f;
-#else
+#ifdef GS_TIMELINE
+        const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+#endif
         {
-#ifdef GS_TIMELINE
-            const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+            // the stage k-tile u - 1 occupied is free (barrier u - 1) and stays free until the loaders are through the epilogue's last barrier
+            const int free_stage = cur == 0 ? S - 1 : cur - 1;
+            float* sw = reinterpret_cast<float*>(lds + free_stage * GS_STAGE_B) + wid * (32 * 64);
+#ifdef ER_GEMM_PROBE_NO_EPILOGUE      // scripts/probes/gemm_stream_probe.hip: what the k-loop costs without the epilogue
+            if (acc[0][0][0] == 12345.678f && acc[1][1][5] == 3.f && acc[0][1][7] == 1.f && acc[1][0][2] == 9.f) sw[lane] = 1.f;
+#else
+            hh_epi_stage<1, 2>(sw, *reinterpret_cast<const f32x16(*)[1][2]>(&acc[0]), lane);
 #endif
-            // the stage k-tile u - 1 occupied is free (barrier u - 1) and stays free until the loaders pass the tile barrier below
-            float* sw = reinterpret_cast<float*>(lds + (cur == 0 ? S - 1 : cur - 1) * GS_STAGE_B) + wid * (32 * 64);
-            if (use_pre) {
-                gemm_hh_epilogue<1, 2, HEPI>(g, sw, *reinterpret_cast<const f32x16(*)[1][2]>(&acc[0]), mw, nw, lane, &pre[0]);
-                gemm_hh_epilogue<1, 2, HEPI>(g, sw, *reinterpret_cast<const f32x16(*)[1][2]>(&acc[1]), mw + 32, nw, lane, &pre[1]);
-            } else {
-                gemm_hh_epilogue<1, 2, HEPI>(g, sw, *reinterpret_cast<const f32x16(*)[1][2]>(&acc[0]), mw, nw, lane);
-                gemm_hh_epilogue<1, 2, HEPI>(g, sw, *reinterpret_cast<const f32x16(*)[1][2]>(&acc[1]), mw + 32, nw, lane);
-            }
-#ifdef GS_TIMELINE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long e1 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long e2 = __builtin_amdgcn_s_memtime();
-            tl_epi += e1 - e0; tl_drain += e2 - e1;
+            epilogue_rows(free_stage, 0, mw, nw, pre[0], use_pre);
+#ifndef ER_GEMM_PROBE_NO_EPILOGUE
+            hh_epi_stage<1, 2>(sw, *reinterpret_cast<const f32x16(*)[1][2]>(&acc[1]), lane);
 #endif
+            epilogue_rows(free_stage, 1, mw, nw, pre[1], use_pre);
         }
+#ifdef GS_TIMELINE
+        const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long e2 = __builtin_amdgcn_s_memtime();
+        tl_epi += e1 - e0; tl_drain += e2 - e1;
 #endif
-        // the loaders may refill the epilogue's stage - once this wave's reads of it have RETURNED (a barrier orders instruction issue, not
-        // the completion of outstanding ds_reads: without the wait the DMA of the next k-tile overtook them - caught by the probe's bit compare)
-        if (jt + 1 < mine) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #undef GS_FRAGS
 #ifdef GS_TIMELINE
