@@ -19,13 +19,16 @@ LIB = os.path.join(PKG, "libedgerunner_hip.so")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified; no kernel of the library needs more than
 # its arch-VGPR budget for them): the softmax / epilogue VALU work reads them in place instead of through v_accvgpr_read / _write copies
 # (flash_attn_hh_kernel: 224 of its 1350 instructions; guided DiT forward 9.02 -> 8.73 ms same box, profiles/r05_ab_mfma_vgpr_form.log)
+# Both are internal LLVM options of ROCm 7.x's hipcc; tests/test_isa_hygiene.py::
+# test_codegen_flags_are_accepted_and_take_effect fails with a clear message if a compiler drops one or stops honouring it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=16",
          "-mllvm", "-amdgpu-mfma-vgpr-form", "-shared", "-fPIC"]
 
 
 def sources():
+    # build.py itself is a source: a change of FLAGS alone must rebuild a stale library
     d = os.path.join(PKG, "csrc")
-    return [os.path.join(d, f) for f in sorted(os.listdir(d))] + [os.path.join(PKG, "..", "include", "edgerunner_hip.h")]
+    return [os.path.join(d, f) for f in sorted(os.listdir(d))] + [os.path.join(PKG, "..", "include", "edgerunner_hip.h"), os.path.abspath(__file__)]
 
 
 def up_to_date() -> bool:

@@ -112,7 +112,8 @@ struct er_ctx {
     bool use_graph = true;
     bool batched = false;     // B > 4 (or ER_FORCE_BATCHED=1): weights streamed once per pass of 32 rows (matrix cores)
     bool batched_valu = false;   // ER_BATCHED_VALU=1: the older VALU kernels (one pass per 16 rows), kept for A/B runs
-    float* skpart = nullptr;  // split-K partials of the batched fc2
+    float* skpart = nullptr;  // split-K partials of the batched projections
+    size_t skpart_floats = 0; // ... and how many floats the block holds (checked by gemv_mfma_groups)
     // fast-mode batches on the matrix cores: activations in the tiled hi | lo operand layout (k_gemv.h xt_entry), one image per producer
     void *xt_h = nullptr, *xt_att = nullptr, *xt_f = nullptr;     // LayerNorm rows (qkv / fc1 input), attention output, fc1 output
     bool xt = false;          // ER_XT=0 keeps the row-major fp32 inputs (A/B + parity matrix)
@@ -655,8 +656,8 @@ static int kv_alloc(er_ctx* c, int batch, int Lcap) {
     c->xt = c->fast && c->batched && !c->batched_valu && !(xe && xe[0] == '0');
     // split-K partials of the batched projections.  A finish launched right behind its producer re-uses ONE [4][32][N] block; only the
     // tiled path defers finishes to a later launch (prep_rows_kernel, sk_part) and keeps a [16][32][hidden] block per group of 32 rows
-    HIPCHK(hipMalloc(&c->skpart, c->xt ? ((b + NBM - 1) / NBM) * (size_t)16 * NBM * (size_t)hid * 4
-                                       : (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size) * 4));
+    c->skpart_floats = c->xt ? ((b + NBM - 1) / NBM) * (size_t)16 * NBM * (size_t)hid : (size_t)4 * NBM * (size_t)std::max(hid, g.vocab_size);
+    HIPCHK(hipMalloc(&c->skpart, c->skpart_floats * 4));
     if (c->xt) {
         const size_t groups = (size_t)(batch + NBM - 1) / NBM;
         const size_t b_h = groups * (size_t)hid * 128, b_f = groups * (size_t)g.intermediate_dim * 128;
@@ -753,8 +754,15 @@ static hipError_t gemv_batched_groups(GemvArgs a, int B, int K, hipStream_t st) 
     return hipSuccess;
 }
 // XT: a.xin is the tiled image of the input (a group of 32 rows is K * 32 floats there as well, so the group offsets coincide)
+struct SkPart { float* p; size_t floats; };       // the context's split-K partial block and its size
 template <typename WT, int EPI, bool XT = false>
-static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStream_t st, bool defer_finish = false, bool narrow = false) {
+static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, SkPart part, hipStream_t st, bool defer_finish = false, bool narrow = false) {
+    {   // the block was sized in er_kv_reserve for K <= 6144 (4 wide / 16 narrow slices) and, when the finish is not deferred, for ONE
+        // group at a time on an in-order stream: refuse anything that would overrun it instead of writing past the end
+        const size_t slices = narrow ? K / (4 * GM_KW) : K / (GM_WAVES * GM_KW), groups = (size_t)(B + NBM - 1) / NBM;
+        const size_t need = (defer_finish ? groups : 1) * slices * NBM * (size_t)a.N;
+        if (!part.p || need > part.floats) return hipErrorInvalidValue;
+    }
     for (int b = 0; b < B; b += NBM) {
         const int nb = (B - b) < NBM ? (B - b) : NBM;
         GemvArgs g = a;
@@ -771,7 +779,7 @@ static hipError_t gemv_mfma_groups(GemvArgs a, int B, int K, float* part, hipStr
         if (g.vcache) g.vcache = (char*)g.vcache + kvb;
         // deferred: every group keeps its own partial block (prep_rows_kernel: g * 4 * 32 * K floats)
         const int slices = narrow ? K / (4 * GM_KW) : K / (GM_WAVES * GM_KW);
-        hipError_t e = launch_gemv_mfma<WT, EPI, XT>(g, nb, K, defer_finish ? part + (long long)(b / NBM) * slices * NBM * a.N : part, st, defer_finish, narrow);
+        hipError_t e = launch_gemv_mfma<WT, EPI, XT>(g, nb, K, defer_finish ? part.p + (long long)(b / NBM) * slices * NBM * a.N : part.p, st, defer_finish, narrow);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -846,9 +854,9 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 a.xin = c->hbuf;
                 a.xt_out = nullptr;
                 if constexpr (HALF) {
-                    if (c->xt) { a.W = L.wqkv_t; a.xin = (const float*)c->xt_h; return gemv_mfma_groups<WT, EPI_QKV, true>(a, B, H, c->skpart, st); }
+                    if (c->xt) { a.W = L.wqkv_t; a.xin = (const float*)c->xt_h; return gemv_mfma_groups<WT, EPI_QKV, true>(a, B, H, SkPart{c->skpart, c->skpart_floats}, st); }
                 }
-                if (!c->batched_valu) { a.W = L.wqkv_t; return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, c->skpart, st); }   // 144 tiles of 32 rows
+                if (!c->batched_valu) { a.W = L.wqkv_t; return gemv_mfma_groups<WT, EPI_QKV>(a, B, H, SkPart{c->skpart, c->skpart_floats}, st); }   // 144 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_QKV>(a, B, H, st);   // 4608 rows = 192 workgroups x 24: one round
             }
             if (layer == 0) return gemv_nw<WT, PRO_EMBED, EPI_QKV>(c->nw_qkv, a, B, H, st);
@@ -878,9 +886,9 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
             if constexpr (HALF) {
                 // 4-wave workgroups (48 row tiles x 4 K-ranges of 384 instead of 48 x one of 1536); + bias + residual happen in fc1's
                 // LayerNorm-rows launch (case 4), which reads the four partials
-                if (c->xt && c->stream_attn && B > 8) { a.W = L.wo_t; a.xin = (const float*)c->xt_att; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, H, c->skpart, st, true, true); }
+                if (c->xt && c->stream_attn && B > 8) { a.W = L.wo_t; a.xin = (const float*)c->xt_att; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, H, SkPart{c->skpart, c->skpart_floats}, st, true, true); }
             }
-            if (c->batched && !c->batched_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, c->skpart, st); }
+            if (c->batched && !c->batched_valu) { a.W = L.wo_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, H, SkPart{c->skpart, c->skpart_floats}, st); }
             if (c->batched) return gemv_batched_groups<WT, 1, 1, EPI_RESID>(a, B, H, st);
             return gemv_groups<WT, 1, 1, PRO_NONE, EPI_RESID, 3>(a, B, H, st);     // 3 waves x 1 row: 512 workgroups = 2 per CU
         }
@@ -903,10 +911,10 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 if constexpr (HALF) {
                     if (c->xt) {      // input and output both tiled: fc2 below reads xt_f
                         a.W = L.w1_t; a.xin = (const float*)c->xt_h; a.xt_out = c->xt_f;
-                        return gemv_mfma_groups<WT, EPI_RELU, true>(a, B, H, c->skpart, st);
+                        return gemv_mfma_groups<WT, EPI_RELU, true>(a, B, H, SkPart{c->skpart, c->skpart_floats}, st);
                     }
                 }
-                if (!c->batched_valu) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, c->skpart, st); }   // 192 tiles of 32 rows
+                if (!c->batched_valu) { a.W = L.w1_t; return gemv_mfma_groups<WT, EPI_RELU>(a, B, H, SkPart{c->skpart, c->skpart_floats}, st); }   // 192 tiles of 32 rows
                 return gemv_batched_groups<WT, 1, 3, EPI_RELU>(a, B, H, st);   // 6144 rows = 256 workgroups x 24
             }
             return gemv_nw<WT, PRO_LN, EPI_RELU>(c->nw_fc1, a, B, H, st);
@@ -918,15 +926,21 @@ static hipError_t launch_kind_t(er_ctx* c, int kind, int layer, hipStream_t st, 
                 // layers 0 .. nl-2 leave the four K-range partials to the next layer's LayerNorm launch (case 0); the last layer finishes
                 // into ypre, which the lm_head reads (after a prefill ypre comes from the GEMM path, so case 6 always reads ypre)
                 // 4-wave workgroups: 48 row tiles x 16 K-ranges of 384 (768 workgroups = 3 per CU instead of 192 on 192 CUs)
-                if (c->xt) { a.W = L.w2_t; a.xin = (const float*)c->xt_f; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, I, c->skpart, st, layer + 1 < nl, true); }
+                if (c->xt) { a.W = L.w2_t; a.xin = (const float*)c->xt_f; return gemv_mfma_groups<WT, EPI_RESID, true>(a, B, I, SkPart{c->skpart, c->skpart_floats}, st, layer + 1 < nl, true); }
             }
-            if (c->batched && !c->batched_valu) { a.W = L.w2_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, c->skpart, st); }   // 48 tiles x 4 K-ranges
+            if (c->batched && !c->batched_valu) { a.W = L.w2_t; return gemv_mfma_groups<WT, EPI_RESID>(a, B, I, SkPart{c->skpart, c->skpart_floats}, st); }   // 48 tiles x 4 K-ranges
             if (c->batched) return gemv_batched_groups<WT, 4, 1, EPI_RESID>(a, B, I, st);
             if constexpr (HALF) {
                 // fast mode, one row: FAT workgroups like qkv's and fc1's - 4 or 6 rows per workgroup instead of 2 (384 / 256 workgroups
                 // instead of 768), so that a CU fetches the 24 KB input vector once or twice instead of three times beside its 72 KB of
                 // fp16 weights: fc2 5.60 -> 5.37 us at 6 rows, 5.68 at 4, ids unchanged (profiles/r05_ab_fc2_rows.log; ER_RW_FC2 = 2 / 4 / 6)
-                static const int rw = [] { const char* v = getenv("ER_RW_FC2"); return v ? atoi(v) : 6; }();
+                // (read ONCE per process, like every A/B knob of the step graph: the graph is captured with the first value; 2 / 4 / 6 only)
+                static const int rw = [] {
+                    const char* v = getenv("ER_RW_FC2");
+                    const int r = v ? atoi(v) : 6;
+                    if (r != 2 && r != 4 && r != 6) fprintf(stderr, "[edgerunner_hip] ER_RW_FC2=%s is not 2 / 4 / 6: using 2 rows per fc2 workgroup\n", v);
+                    return r;
+                }();
                 if (B == 1 && rw == 6) return launch_gemv<WT, 4, 1, 6, PRO_NONE, EPI_RESID>(a, st);
                 if (B == 1 && rw == 4) return launch_gemv<WT, 4, 1, 4, PRO_NONE, EPI_RESID>(a, st);
             }
@@ -1583,12 +1597,12 @@ extern "C" int er_k_gemv(const float* w, const float* bias, const float* x, cons
         GemvArgs am = a;
         am.W = wt;
         if (k == 1536) {
-            if (relu && !resid) e = valu ? gemv_batched_groups<float, 1, 2, EPI_RELU>(a, B, k, st) : gemv_mfma_groups<float, EPI_RELU>(am, B, k, part, st);
+            if (relu && !resid) e = valu ? gemv_batched_groups<float, 1, 2, EPI_RELU>(a, B, k, st) : gemv_mfma_groups<float, EPI_RELU>(am, B, k, SkPart{part, (size_t)4 * NBM * n}, st);
             else if (!relu && !resid) e = gemv_batched_groups<float, 1, 1, EPI_STORE>(a, B, k, st);   // narrow: VALU kernel, as in the decode step
             else if (!relu && resid) e = gemv_batched_groups<float, 1, 1, EPI_RESID>(a, B, k, st);
             else e = hipErrorInvalidValue;
         } else if (k == 6144 && !relu && resid && !ln_w) {
-            e = valu ? gemv_batched_groups<float, 4, 1, EPI_RESID>(a, B, k, st) : gemv_mfma_groups<float, EPI_RESID>(am, B, k, part, st);
+            e = valu ? gemv_batched_groups<float, 4, 1, EPI_RESID>(a, B, k, st) : gemv_mfma_groups<float, EPI_RESID>(am, B, k, SkPart{part, (size_t)4 * NBM * n}, st);
         } else {
             e = hipErrorInvalidValue;
         }
@@ -1738,14 +1752,16 @@ extern "C" int er_k_gemm_hh_geglu(const float* a, const void* w, const float* bi
                                   void* stream) {
     // out16[m][f] = fp16(GEGLU(fp16(a) . w^T + bias)), w = the [2f][k] fp16 weight in the checkpoint's order (value rows, then gate rows):
     // the entry builds the permuted copy the product keeps per layer (geglu_permute_kernel) and runs the fused kernel
+    if (!a || !w || !bias || !out16) return fail(ER_ERR_INVALID, "er_k_gemm_hh_geglu: a, w, bias and out16 are required (the permute pass reads the bias)");
     if (k % 64 || f % 64 || m <= 0) return fail(ER_ERR_INVALID, "er_k_gemm_hh_geglu: k and f must be multiples of 64");
     if (force_tile != 0 && force_tile != 1 && force_tile != 2 && force_tile != 4) return fail(ER_ERR_INVALID, "er_k_gemm_hh_geglu: force_tile 0 / 1 / 2 / 4");
     hipStream_t st = (hipStream_t)stream;
-    _Float16 *a16 = nullptr, *wp = nullptr;
-    float* bp = nullptr;
-    HIPCHK(hipMalloc(&a16, (size_t)m * k * sizeof(_Float16)));
-    HIPCHK(hipMalloc(&wp, (size_t)2 * f * k * sizeof(_Float16)));
-    HIPCHK(hipMalloc(&bp, (size_t)2 * f * sizeof(float)));
+    // ONE scratch block, carved: fp16 copy of a | permuted weight | permuted bias (an early return on a failed allocation leaks nothing)
+    const size_t na = ((size_t)m * k * sizeof(_Float16) + 255) & ~(size_t)255, nw = ((size_t)2 * f * k * sizeof(_Float16) + 255) & ~(size_t)255;
+    char* blk = nullptr;
+    HIPCHK(hipMalloc((void**)&blk, na + nw + (size_t)2 * f * sizeof(float)));
+    _Float16 *a16 = reinterpret_cast<_Float16*>(blk), *wp = reinterpret_cast<_Float16*>(blk + na);
+    float* bp = reinterpret_cast<float*>(blk + na + nw);
     hipLaunchKernelGGL(cvt_rows_f16_kernel, dim3(ew_grid((long long)m * k)), dim3(ER_WG), 0, st, a, a16, (long long)m, k, k, k);
     hipLaunchKernelGGL(geglu_permute_kernel, dim3(2 * f), dim3(ER_WG), 0, st, reinterpret_cast<const _Float16*>(w), bias, wp, bp, f, k);
     GemmArgs g = gemm_args_default();
@@ -1754,7 +1770,7 @@ extern "C" int er_k_gemm_hh_geglu(const float* a, const void* w, const float* bi
     g.c16 = reinterpret_cast<_Float16*>(out16); g.ldc16 = f;
     hipError_t e = launch_gemm_hh_geglu(g, st, force_tile);
     hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(a16); hipFree(wp); hipFree(bp);
+    hipFree(blk);
     HIPRET(e);
     HIPRET(e2);
     return ER_OK;

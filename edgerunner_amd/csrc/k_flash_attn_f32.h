@@ -254,12 +254,16 @@ inline int flash32_waves(int N, int H, int B) {
     const long long wg4 = (long long)((N + 4 * FA32_QW - 1) / (4 * FA32_QW)) * H * B;
     return (forced == 2 || forced == 4) ? forced : (wg4 < 768 ? 2 : 4);
 }
-// Key-range split of the causal D = 96 launch (KSP): on wherever the launch runs two-wave workgroups, i.e. the single-prefix prefill
-// (encode + prefill 38.3 -> 37.9 ms, profiles/r05_ksplit.log); ER_FLASH32_KSPLIT=0 turns it off.  ONE rule for the callers that
-// allocate the partial buffers and for the launcher that uses them.
+// Key-range split of the causal D = 96 launch (KSP): for ONE sample whose launch runs two-wave workgroups, i.e. the single-prefix
+// prefill (encode + prefill 38.3 -> 37.9 ms, profiles/r05_ksplit.log); ER_FLASH32_KSPLIT=0 turns it off.  B == 1 explicitly (round 6,
+// ADVICE r5): the merge rounds differently from the unsplit kernel by a few ulp, and up to round 5 a pair of prompts (B = 2 also runs
+// two-wave workgroups) took the split while the same prompts in a batch of three did not - now every batch of two or more gives a
+// prompt the unsplit kernel's bits whatever its size (tests/test_gpu_kernels.py::test_flash_attn_f32_batch_invariance); a prompt
+// prefilled ALONE differs from them by the merge's rounding.  ONE rule for the callers that allocate the partial buffers and for the
+// launcher that uses them.
 inline bool flash32_ksplit(int N, int H, int B, int D, bool causal) {
     const char* v = getenv("ER_FLASH32_KSPLIT");           // read per call (the tests compare both forms in one process)
-    return !(v && atoi(v) == 0) && causal && D == 96 && flash32_waves(N, H, B) == 2;
+    return !(v && atoi(v) == 0) && causal && D == 96 && B == 1 && flash32_waves(N, H, B) == 2;
 }
 
 inline hipError_t launch_flash_attn_f32(const Flash32Args& a, int D, bool causal, int H, int B, hipStream_t st) {

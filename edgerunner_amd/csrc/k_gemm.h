@@ -1030,7 +1030,8 @@ inline hipError_t launch_gemm_f16(const GemmArgs& g, hipStream_t st) {   // NT o
 // qkv product - it measured slower than 128 x 128: 47.6 vs 41.5 us, profiles/r05_gemm_hh256_probe.log):
 // ER_GEMM256=0 restores the round-4 rule
 inline bool gemm_hh_use_256(int M, int N) {
-    static const bool off = [] { const char* v = getenv("ER_GEMM256"); return v && atoi(v) == 0; }();
+    const char* v = getenv("ER_GEMM256");                  // read per launch, like ER_GEMM_TILE / ER_FLASH32_KSPLIT: a test or an A/B script may flip it in-process
+    const bool off = v && atoi(v) == 0;
     const long long t = (long long)((M + 255) / 256) * ((N + 255) / 256);
     return !off && t >= 256;
 }

@@ -31,11 +31,13 @@ def kernels(tmp_path_factory):
     for name, body in re.findall(r"\n(_Z[^\n:]*):\s*; @[^\n]*\n(.*?)s_endpgm", text, flags=re.S):
         funcs[name] = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith((";", "."))]
     assert len(funcs) > 200, "device assembly not parsed"
+    # kernel descriptors: {mangled name: preloaded kernel-argument SGPRs}
+    funcs["__preload__"] = {n: int(v) for n, v in re.findall(r"\.amdhsa_kernel (\S+)\n(?:.*\n)*?\s*\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text)}
     return funcs
 
 
 def select(kernels, pattern):
-    sel = {n: b for n, b in kernels.items() if re.search(pattern, n)}
+    sel = {n: b for n, b in kernels.items() if not n.startswith("__") and re.search(pattern, n)}
     assert sel, f"no kernel matches {pattern}"
     return sel
 
@@ -165,3 +167,33 @@ def test_gemm_hh256_main_loop_shape(kernels):
         vm = [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l]
         assert vm == ["s_waitcnt vmcnt(0) lgkmcnt(0)"], (n, vm)
         assert count(b, "global_load_lds_dwordx4") == 16, (n, "8 pieces in the prologue + 8 in the loop")
+
+
+def test_codegen_flags_are_accepted_and_take_effect(kernels, tmp_path):
+    """build.py compiles the whole library with two internal LLVM options (-amdgpu-kernarg-preload-count=16, -amdgpu-mfma-vgpr-form).
+    A hipcc that no longer knows one of them must fail HERE with a clear message (not as an "Unknown command line argument" in the
+    middle of build()), and each must still do what the kernels were tuned for: the MFMA kernels keep their accumulators in VGPRs (no
+    v_accvgpr copies in the LDS-DMA attention kernel, no MFMA kernel spilling to scratch under the 256-VGPR cap the flag implies), and
+    the single-row decode kernels receive their leading scalar arguments preloaded (no s_load of kernel arguments in front of the
+    first vector load)."""
+    from edgerunner_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "probe.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(float* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 1.f; }\n")
+    for i, f in enumerate(B.FLAGS):
+        if f != "-mllvm":
+            continue
+        opt = B.FLAGS[i + 1]
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "--cuda-device-only", "-c", "-mllvm", opt, "-o", str(tmp_path / "probe.o"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, f"this hipcc rejects `-mllvm {opt}` (edgerunner_amd/build.py FLAGS; INTEGRATION.md section 3): {r.stderr[-400:]}"
+    # -amdgpu-mfma-vgpr-form: accumulators in VGPRs, and nothing spills under the cap
+    for n, b in select(kernels, r"flash_attn_hh_kernel|flash_attn_f16_kernel").items():
+        assert not count(b, "v_accvgpr_read") and not count(b, "v_accvgpr_write"), (n, "MFMA accumulators are copied through AGPRs again")
+    for n, b in kernels.items():
+        if not n.startswith("__") and count(b, "v_mfma_"):
+            assert not [l for l in b if l.startswith("scratch_")], (n, "an MFMA kernel spills to scratch")
+    # -amdgpu-kernarg-preload-count: plen / q / cache pointers of the balanced attention kernel and the single-row GEMVs arrive in SGPRs
+    pre = kernels["__preload__"]
+    hot = {n: v for n, v in pre.items() if re.search(r"attn_decode3_kernel|gemv_kernelI(f|DF16_)Li1E|outproj_merge_kernel", n)}
+    assert hot and all(v >= 8 for v in hot.values()), ({n: v for n, v in hot.items() if v < 8}, "leading kernel arguments are not preloaded into SGPRs")
