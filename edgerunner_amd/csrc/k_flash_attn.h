@@ -424,249 +424,13 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The same attention as an EIGHT-wave workgroup in which the two waves of a SIMD run in ANTI-PHASE (round 6).  The 4-wave kernel's
-// waves share their SIMD with a wave of ANOTHER workgroup, with which nothing aligns them: an in-order wave that wants the matrix
-// pipe while its neighbour's eight MFMAs are in it waits, and only then starts its ~200 softmax instructions - 2830 cycles per key tile
-// and wave for 512 cycles of MFMA and ~530 of VALU (profiles/r06_flash_hh_timeline_before.log), 2500 per tile with the scores of the
-// next tile issued ahead of the softmax (flash_attn_hh_kernel above).  Here waves 0..3 (role A) and 4..7 (role B; wave w and w + 4
-// share a SIMD) alternate a MATRIX phase - S^T(t) = K(t) Q^T, then O^T += V^T(t - 1) P^T(t - 1) - and a SOFTMAX phase, B one
-// phase behind A, every phase closed by the workgroup barrier: while a SIMD's A wave is in the matrix pipe its B wave runs its softmax
-// on the VALU, and the other way round.  Global phases g = 0 .. 2 n + 1 for n key tiles:
-//     role A: g = 2 t: matrix phase of tile t      g = 2 t + 1: softmax of tile t
-//     role B: g = 2 t + 1: matrix phase of tile t  g = 2 t + 2: softmax of tile t
-// Key tile u is read in phases 2 u .. 2 u + 3: its K / V^T images (LDS-DMA, 16 pieces, two per wave) are waited for at the end of
-// phase 2 u - 1 and its ring stage takes tile u + 6 at the start of phase 2 u + 4 (six stages, 96 KB, one workgroup per CU).
-// 256 queries per workgroup (32 per wave): the DiT's 2048 latent tokens x 16 heads x 2 = 256 workgroups.  Same arithmetic in the same
-// order per element as flash_attn_hh_kernel / flash_attn_f16_kernel: bit-identical results.
-constexpr int FA8_NST = 6, FA8_WAVES = 8;
-template <int NOUT> __device__ __forceinline__ void fa8_wait_pieces() {
-    if constexpr (NOUT >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (NOUT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (NOUT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (NOUT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (NOUT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ void fa8_wait_tiles(int allowed) {      // at most `allowed` of this wave's tiles (two pieces each) still in flight
-    if (allowed >= 5) fa8_wait_pieces<10>();
-    else if (allowed == 4) fa8_wait_pieces<8>();
-    else if (allowed == 3) fa8_wait_pieces<6>();
-    else if (allowed == 2) fa8_wait_pieces<4>();
-    else if (allowed == 1) fa8_wait_pieces<2>();
-    else fa8_wait_pieces<0>();
-}
-
-__global__ __launch_bounds__(64 * FA8_WAVES) void flash_attn_hh8_kernel(FlashHArgs a) {
-    constexpr int TILE = 64 * 64, NST = FA8_NST;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[NST * 2 * TILE];   // [stage][K | Vt][64 rows][64]: the ONLY LDS object
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, half = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (FA8_WAVES * FA_QW) + wid * FA_QW;
-    const _Float16* Q = a.Q + b * a.qs_b + h * a.head_stride;
-    const _Float16* K = a.K + b * a.ks_b + h * a.head_stride;
-    const _Float16* Vt = a.Vt + b * a.vts_b + h * a.vts_h;
-    _Float16* O16 = a.O16 + b * a.os_b + h * a.head_stride;
-    fa_h8 qb[4];
-    {
-        const _Float16* qr = Q + (long long)min(q0 + li, a.N - 1) * a.ldq;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qb[ks] = *reinterpret_cast<const fa_h8*>(qr + ks * 16 + half * 8);
-    }
-    asm volatile("" :: "v"(qb[0]), "v"(qb[1]), "v"(qb[2]), "v"(qb[3]));       // consumed here (see flash_attn_hh_kernel)
-    // this wave's two LDS-DMA pieces of a tile: rows 8 w .. 8 w + 7 of K and of V^T
-    const int lrow = lane >> 3, lslot = lane & 7;
-    const int prow = 8 * wid + lrow, psl = (lslot ^ ((prow >> 1) & 7)) << 3;
-    const _Float16* pk = K + psl;                                       // + (clamped key) * ldk per tile
-    const _Float16* pv = Vt + (long long)prow * a.ldvt + psl;           // + kbase per tile
-    const unsigned lds_base = (unsigned)(unsigned long long)(fa_lptr)lds;
-    const int n = (a.M + FA_KT - 1) / FA_KT;
-    int st_issue = 0;                                                   // ring stage of the next tile to issue (tile u lives in stage u % NST)
-    auto issue = [&](int t) {
-        const int kbase = t * FA_KT;
-        const unsigned ks_ = lds_base + (unsigned)(st_issue * 2 * TILE + 8 * wid * 64) * 2u;
-        fa_glds16(pk + (long long)min(kbase + prow, a.M - 1) * a.ldk, ks_);
-        fa_glds16(pv + kbase, ks_ + TILE * 2u);
-        st_issue = st_issue + 1 == NST ? 0 : st_issue + 1;
-    };
-    fa_f16v ot[2], st0[2], st1[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[db][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const int swz = (li >> 1) & 7;
-    const float sl2 = a.scale * 1.4426950408889634f;       // base-2 softmax, see flash_attn_f16_kernel
-    auto scores = [&](int t, fa_f16v (&st)[2]) {
-        const _Float16* Ks = lds + (t % NST) * 2 * TILE;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const fa_h8 ka = *reinterpret_cast<const fa_h8*>(Ks + (kb * 32 + li) * 64 + (((2 * ks + half) ^ swz) << 3));
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb[ks], st[kb], 0, 0, 0);
-            }
-        }
-    };
-    auto softmax = [&](int t, fa_f16v (&st)[2]) {
-        const int kbase = t * FA_KT;
-        float mloc = -INFINITY;
-        if (kbase + FA_KT <= a.M) {                  // wave-uniform: only the last tile can hold keys beyond M
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) mloc = fmaxf(fmaxf(mloc, st[kb][r]), st[kb][r + 1]);
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float s = key < a.M ? st[kb][r] : -INFINITY;
-                    st[kb][r] = s;
-                    mloc = fmaxf(mloc, s);
-                }
-        }
-        mloc = xor_max<32>(mloc) * sl2;
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(st[kb][r], sl2, -m_new));
-                st[kb][r] = p;
-                psum += p;
-            }
-        l_run = l_run * alpha + psum;
-        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull) {      // wave-uniform: no query of this wave met a new maximum -> alpha = 1
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
-        }
-        m_run = m_new;
-    };
-    auto pv_acc = [&](int t, const fa_f16v (&st)[2]) {
-        const _Float16* Vs = lds + (t % NST) * 2 * TILE + TILE;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int stp = 0; stp < 2; ++stp) {
-                const fa_h8 pb = {(_Float16)st[kb][8 * stp + 0], (_Float16)st[kb][8 * stp + 1], (_Float16)st[kb][8 * stp + 2],
-                                  (_Float16)st[kb][8 * stp + 3], (_Float16)st[kb][8 * stp + 4], (_Float16)st[kb][8 * stp + 5],
-                                  (_Float16)st[kb][8 * stp + 6], (_Float16)st[kb][8 * stp + 7]};
-                const int c0 = kb * 4 + 2 * stp + half;               // (fa_vt_pos: the lane half's 8 keys of the step are ONE 16-byte chunk)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const fa_h8 va = *reinterpret_cast<const fa_h8*>(Vs + (db * 32 + li) * 64 + ((c0 ^ swz) << 3));
-                    ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, ot[db], 0, 0, 0);
-                }
-            }
-    };
-    // ---- prologue: tiles 0 .. 5 requested, tile 0 in LDS for everybody
-    const int npro = n < NST ? n : NST;
-    for (int t = 0; t < npro; ++t) issue(t);
-    fa8_wait_tiles(npro - 1);
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phases.  Start of an even phase g >= 4: tile g / 2 - 2 has been read for the last time (phase g - 1), its stage takes tile
-    // g / 2 + 4.  End of an odd phase g: tile u = (g + 1) / 2 is needed from phase g + 1 on; tiles up to max(5, u + 3) are requested.
-    const int role = wid >> 2, nph = 2 * n + 2;
-    auto phase_edges_begin = [&](int g) {
-        if (!(g & 1) && g >= 4 && (g >> 1) + 4 < n) issue((g >> 1) + 4);
-    };
-#ifdef FA_TIMELINE
-    unsigned long long f8[4] = {0, 0, 0, 0}, f8_last = __builtin_amdgcn_s_memtime();
-#define F8_TP(i) do { asm volatile("s_nop 0" :: "v"(st0[0]), "v"(st0[1]), "v"(st1[0]), "v"(st1[1]), "v"(ot[0]), "v"(ot[1])); const unsigned long long c_ = __builtin_amdgcn_s_memtime(); \
-                      f8[i] += c_ - f8_last; f8_last = c_; } while (0)
-#else
-#define F8_TP(i)
-#endif
-    auto phase_end = [&](int g) {
-        F8_TP(((g & 1) == (wid >> 2)) ? 0 : 1);                  // 0: matrix phase work, 1: softmax phase work
-        if (g & 1) {
-            const int u = (g + 1) >> 1;
-            if (u < n) fa8_wait_tiles(min(max(5, u + 3), n - 1) - u);
-        }
-        F8_TP(2);
-        asm volatile("s_barrier" ::: "memory");
-        F8_TP(3);
-    };
-    // one block of four phases = two key tiles per role; the score / probability registers alternate st0 (even tiles) / st1 (odd tiles)
-    for (int g0 = 0; g0 < nph; g0 += 4) {
-        const int k2 = g0 >> 1;                                          // = 2 k: the even tile of this block
-        if (role == 0) {
-            // g0: matrix phase of tile 2k            g0 + 1: softmax(2k)       g0 + 2: matrix phase of tile 2k + 1      g0 + 3: softmax(2k + 1)
-            phase_edges_begin(g0);
-            if (k2 < n) scores(k2, st0);
-            if (k2 >= 1 && k2 - 1 < n) pv_acc(k2 - 1, st1);
-            phase_end(g0);
-            if (g0 + 1 < nph) { phase_edges_begin(g0 + 1); if (k2 < n) softmax(k2, st0); phase_end(g0 + 1); }
-            if (g0 + 2 < nph) {
-                phase_edges_begin(g0 + 2);
-                if (k2 + 1 < n) scores(k2 + 1, st1);
-                if (k2 < n) pv_acc(k2, st0);
-                phase_end(g0 + 2);
-            }
-            if (g0 + 3 < nph) { phase_edges_begin(g0 + 3); if (k2 + 1 < n) softmax(k2 + 1, st1); phase_end(g0 + 3); }
-        } else {
-            // g0: softmax(2k - 1)     g0 + 1: matrix phase of tile 2k     g0 + 2: softmax(2k)     g0 + 3: matrix phase of tile 2k + 1
-            phase_edges_begin(g0);
-            if (k2 >= 1 && k2 - 1 < n) softmax(k2 - 1, st1);
-            phase_end(g0);
-            if (g0 + 1 < nph) {
-                phase_edges_begin(g0 + 1);
-                if (k2 < n) scores(k2, st0);
-                if (k2 >= 1 && k2 - 1 < n) pv_acc(k2 - 1, st1);
-                phase_end(g0 + 1);
-            }
-            if (g0 + 2 < nph) { phase_edges_begin(g0 + 2); if (k2 < n) softmax(k2, st0); phase_end(g0 + 2); }
-            if (g0 + 3 < nph) {
-                phase_edges_begin(g0 + 3);
-                if (k2 + 1 < n) scores(k2 + 1, st1);
-                if (k2 < n) pv_acc(k2, st0);
-                phase_end(g0 + 3);
-            }
-        }
-    }
-#ifdef FA_TIMELINE
-    if (lane == 0) {
-        float* o_ = fa_timeline_out + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wid * 4;
-        for (int i = 0; i < 4; ++i) o_[i] = (float)f8[i] / nph;
-    }
-#endif
-    const float l_tot = xor_sum<32>(l_run);
-    const int q = q0 + li;
-    if (q < a.N) {
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {                        // registers r .. r+3 = 4 consecutive head dims
-                const long long o = (long long)q * a.ldo + db * 32 + 8 * (r >> 2) + 4 * half;
-                *reinterpret_cast<fa_h4*>(O16 + o) = (fa_h4){(_Float16)(ot[db][r] / l_tot), (_Float16)(ot[db][r + 1] / l_tot),
-                                                             (_Float16)(ot[db][r + 2] / l_tot), (_Float16)(ot[db][r + 3] / l_tot)};
-            }
-    }
-}
-
-// the eight-wave anti-phase kernel wherever its 256-query workgroups fill at least half the chip (the DiT's self- and cross-attention:
-// 256 workgroups); ER_FLASH_HH8=0 keeps the four-wave kernel (A/B, parity matrix: identical bits)
-inline bool flash_hh_use8(int N, int H, int B) {
-    const char* v = getenv("ER_FLASH_HH8");                 // read per launch
-    if (v && atoi(v) == 0) return false;
-    return (long long)((N + FA8_WAVES * FA_QW - 1) / (FA8_WAVES * FA_QW)) * H * B >= 128 || (v && atoi(v) == 1);
-}
+// (Round 6 also measured an EIGHT-wave workgroup in which the two waves of a SIMD alternate a matrix phase and a softmax phase in
+// anti-phase, every phase closed by the workgroup barrier - commit 44ab76c, profiles/r06_flash_hh8_ab.log, r06_flash_hh8_timeline.log:
+// 72 us against 54.4 for the 2048 x 2048 self-attention.  A wave that has a pipe to itself still needs ~1400 cycles for its eight S +
+// eight P V MFMAs with their sixteen fragment reads, and ~1400 for its ~200 softmax instructions: one wave issues an instruction
+// every 4-7 cycles, so the phases are issue-bound, not pipe-bound, and the barrier per phase (440 cycles) comes on top.  s_setprio 1
+// around the score MFMAs: equal, 54.5 vs 54.8 us, r06_flash_hh_setprio_ab.log.)
 inline hipError_t launch_flash_attn_hh(const FlashHArgs& a, int H, int B, hipStream_t st) {
-    if (flash_hh_use8(a.N, H, B)) {
-        dim3 grid8((a.N + FA8_WAVES * FA_QW - 1) / (FA8_WAVES * FA_QW), H, B);
-        hipLaunchKernelGGL(flash_attn_hh8_kernel, grid8, dim3(64 * FA8_WAVES), 0, st, a);
-        return hipGetLastError();
-    }
     dim3 grid((a.N + ER_NWAVES * FA_QW - 1) / (ER_NWAVES * FA_QW), H, B);
     hipLaunchKernelGGL(flash_attn_hh_kernel, grid, dim3(ER_WG), 0, st, a);
     return hipGetLastError();

@@ -28,11 +28,10 @@ int main() {
         fh.ldq = fh.ldk = 3 * C; fh.ldvt = M == 2048 ? N : 320; fh.ldo = C;
         fh.qs_b = fh.ks_b = (long long)N * 3 * C; fh.vts_h = 64LL * fh.ldvt; fh.vts_b = (long long)H * 64 * fh.ldvt; fh.os_b = (long long)N * C;
         fh.head_stride = D; fh.scale = 0.125f;
-        const bool k8 = flash_hh_use8(N, H, B);
-        const int nwg = (N / (k8 ? 256 : 128)) * H * B;
+        const int nwg = (N / 128) * H * B;
         float* dbg;
-        CHECK(hipMalloc(&dbg, (size_t)nwg * 32 * 4));
-        CHECK(hipMemset(dbg, 0, (size_t)nwg * 32 * 4));
+        CHECK(hipMalloc(&dbg, (size_t)nwg * 16 * 4));
+        CHECK(hipMemset(dbg, 0, (size_t)nwg * 16 * 4));
 #ifdef FA_TIMELINE
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(fa_timeline_out), &dbg, sizeof(dbg)));
 #endif
@@ -50,21 +49,13 @@ int main() {
         CHECK(hipStreamSynchronize(st));
         float ms;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
-        std::vector<float> d((size_t)nwg * (k8 ? 32 : 16));
+        std::vector<float> d((size_t)nwg * 16);
         CHECK(hipMemcpy(d.data(), dbg, d.size() * 4, hipMemcpyDeviceToHost));
         double m[4] = {0, 0, 0, 0};
         for (size_t i = 0; i < d.size(); ++i) m[i & 3] += d[i] / (d.size() / 4);
         const double us = ms * 1e3 / reps, flop = 4.0 * B * H * (double)N * fh.M * D;
         const int ntiles = (fh.M + 63) / 64;
-        if (k8) {
-            double ra[4] = {0, 0, 0, 0};
-            for (size_t i = 0; i < d.size(); ++i) ra[i & 3] += d[i] / (d.size() / 4);
-            printf("%d keys, eight-wave anti-phase kernel: %7.1f us per launch (%6.1f TFLOP/s); cycles per PHASE and wave (mean over both roles; a wave's matrix "
-                   "and softmax phases alternate): matrix-phase work %5.0f | softmax-phase work %5.0f | DMA wait %5.0f | barrier %5.0f; %d phases\n", fh.M, us, flop / us / 1e6,
-                   2 * ra[0], 2 * ra[1], ra[2], ra[3], 2 * ntiles + 2);
-            hipFree(qkv); hipFree(vt); hipFree(o); hipFree(dbg);
-            continue;
-        }
+
         printf("%d keys: %7.1f us per launch (%6.1f TFLOP/s);  cycles per key tile and wave: wait + barrier + DMA issue %5.0f | S = K Q^T %5.0f | softmax %5.0f | "
                "P V %5.0f | sum %5.0f x %d tiles = %.0f cycles -> clock ~%.2f GHz if the loop is the launch\n", fh.M, us, flop / us / 1e6, m[0], m[1], m[2], m[3],
                m[0] + m[1] + m[2] + m[3], ntiles, (m[0] + m[1] + m[2] + m[3]) * ntiles, (m[0] + m[1] + m[2] + m[3]) * ntiles / (us - 2.0) / 1e3);
