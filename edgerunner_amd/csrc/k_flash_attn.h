@@ -210,24 +210,12 @@ __device__ __forceinline__ void fa_glds16(const void* gsrc, unsigned lds_byte_ad
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-#ifdef FA_TIMELINE      // scripts/probes/flash_hh_timeline_probe.hip: cycles per key tile in wait + barrier / S = K Q^T / softmax / P V
-__device__ float* fa_timeline_out;
-#else
-#define FA_TP(i)
-#endif
 __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
     constexpr int TILE = 64 * 64;                                   // halves per K (or V^T) tile image
-    // FIVE stages (80 KB: two workgroups per CU): a key tile is only 16 MFMAs per wave while a tile's LDS-DMA takes 1-3 us to land with
-    // 512 workgroups loading at once - with two stages the kernel waited for memory on every tile (profiles/r03_dit_*: 146 us for the
-    // 2048 x 2048 self-attention).  Two tiles stay in flight across the (raw) barrier behind the two the loop is working on; waits are
-    // counted, never vmcnt(0) in the steady state.
-    // Round 6: the loop is SOFTWARE-PIPELINED - S^T(t + 1) = K(t + 1) Q^T is issued BEFORE the softmax of tile t, so the matrix pipe
-    // works through those eight MFMAs while the wave runs the ~200 VALU instructions of the softmax, and P(t) V(t) queues behind them.
-    // The serial form (S, softmax, P V per tile) spent 2830 cycles per tile and wave for 512 cycles of MFMA and ~500 of VALU
-    // (profiles/r06_flash_hh_timeline_before.log: wait + barrier 698 | S 333 | softmax 1205 | P V 595) - the two waves a SIMD holds
-    // did not hide each other's phases.  The tile whose K is read is one ahead of the tile whose V is read, hence the fifth stage.
-    // Same arithmetic in the same order per element: bit-identical to the serial form and to flash_attn_f16_kernel.
-    constexpr int NST = 5;
+    // FOUR stages: a key tile is only 16 MFMAs per wave (~0.25 us) while a tile's LDS-DMA takes 1-3 us to land with 512 workgroups
+    // loading at once - with two stages the kernel waited for memory on every tile (profiles/r03_dit_*: 146 us for the 2048 x 2048
+    // self-attention).  Three tiles stay in flight across the (raw) barrier; waits are counted, never vmcnt(0) in the steady state.
+    constexpr int NST = 4;
     __shared__ __attribute__((aligned(16))) _Float16 lds[NST * 2 * TILE];   // [stage][K | Vt][64 rows][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,11 +250,9 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
         pv[j] = Vt + (long long)r * a.ldvt + sl;                    // + kbase per tile
     }
     const unsigned lds_base = (unsigned)(unsigned long long)(fa_lptr)lds;
-    const int ntiles = (a.M + FA_KT - 1) / FA_KT;
-    int st_issue = 0;                                               // ring stage of the next tile to issue (tile u lives in stage u % NST)
-    auto issue = [&](int t) {
+    auto issue = [&](int t, int s) {
         const int kbase = t * FA_KT;
-        const unsigned ks_ = lds_base + (unsigned)(st_issue * 2 * TILE + 8 * 2 * wid * 64) * 2u;      // bytes; this wave's first piece
+        const unsigned ks_ = lds_base + (unsigned)(s * 2 * TILE + 8 * 2 * wid * 64) * 2u;      // bytes; this wave's first piece
         const unsigned vs_ = ks_ + TILE * 2u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -275,19 +261,6 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) fa_glds16(pv[j] + kbase, vs_ + j * 8 * 64 * 2u);
-        st_issue = st_issue + 1 == NST ? 0 : st_issue + 1;
-    };
-    // tile u has landed when at most the pieces of the tiles issued after it (4 per tile and wave; tiles <= u + 2 are issued when this
-    // runs) are outstanding.  Wait and barrier in ONE statement: the s_barrier builtin carries no fence, so nothing else would keep a
-    // compiler-scheduled fragment read from moving between the counted wait and the barrier.  (The counts assume the loop issues no
-    // other VMEM operation - no scratch: tests/test_isa_hygiene.py checks the kernel for both.)  Behind the barrier everybody's pieces
-    // of tile u are in LDS and everybody is through P V of tile u - 2: its stage takes tile u + 3.
-    auto wait_and_issue = [&](int u) {
-        const int ahead = min(2, ntiles - 1 - u);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (u + 3 < ntiles) issue(u + 3);
     };
 
     fa_f16v ot[2];
@@ -297,16 +270,26 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
         for (int r = 0; r < 16; ++r) ot[db][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const int swz = (li >> 1) & 7;
+    const int ntiles = (a.M + FA_KT - 1) / FA_KT;
     const float sl2 = a.scale * 1.4426950408889634f;       // base-2 softmax, see flash_attn_f16_kernel
-    fa_f16v stA[2], stB[2];
-#ifdef FA_TIMELINE
-    unsigned long long fa_tl[4] = {0, 0, 0, 0}, fa_last = __builtin_amdgcn_s_memtime();
-#define FA_TP(i) do { asm volatile("s_nop 0" :: "v"(stA[0]), "v"(stA[1]), "v"(stB[0]), "v"(stB[1]), "v"(ot[0]), "v"(ot[1])); const unsigned long long c_ = __builtin_amdgcn_s_memtime(); \
-                      fa_tl[i] += c_ - fa_last; fa_last = c_; } while (0)
-#endif
-    // S^T of the tile in ring stage `stage`
-    auto scores = [&](int stage, fa_f16v (&st)[2]) {
-        const _Float16* Ks = lds + stage * 2 * TILE;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < ntiles) issue(p, p);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kbase = t * FA_KT, cur = t & (NST - 1);
+        // tile t has landed when at most the pieces of the tiles issued after it (4 per tile and wave) are outstanding
+        const int ahead = min(NST - 2, ntiles - 1 - t);
+        // wait and barrier in ONE statement: the s_barrier builtin carries no fence, so nothing else would keep a compiler-scheduled
+        // fragment read from moving between the counted wait and the barrier.  (The counts assume the loop issues no other VMEM
+        // operation - no scratch: tests/test_isa_hygiene.py checks the kernel for both.)
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // everybody's pieces of tile t are in LDS; everybody is done reading tile t - 1
+        if (t + NST - 1 < ntiles) issue(t + NST - 1, (t + NST - 1) & (NST - 1));      // into the stage tile t - 1 just vacated
+        const _Float16* Ks = lds + cur * 2 * TILE;
+        const _Float16* Vs = Ks + TILE;
+        fa_f16v st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -317,11 +300,6 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb[ks], st[kb], 0, 0, 0);
             }
         }
-    };
-    // softmax of tile t (scores in st) and O^T += V^T(t) P^T
-    auto softmax_pv = [&](int t, int stage, fa_f16v (&st)[2]) {
-        const int kbase = t * FA_KT;
-        const _Float16* Vs = lds + stage * 2 * TILE + TILE;
         float mloc = -INFINITY;
         if (kbase + FA_KT <= a.M) {                  // wave-uniform: only the last tile can hold keys beyond M
 #pragma unroll
@@ -359,7 +337,6 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
                 for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
         }
         m_run = m_new;
-        FA_TP(2);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -376,40 +353,7 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
                     ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, ot[db], 0, 0, 0);
                 }
             }
-        FA_TP(3);
-    };
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-        if (p < ntiles) issue(p);
-    wait_and_issue(0);
-    scores(0, stA);
-    int stage = 0;                                                  // ring stage of tile t
-    for (int t = 0; t < ntiles; t += 2) {
-        const int s1 = stage + 1 == NST ? 0 : stage + 1, s2 = s1 + 1 == NST ? 0 : s1 + 1;
-        // stA holds S^T(t); S^T(t + 1) goes out in front of the softmax of tile t
-        if (t + 1 < ntiles) {
-            wait_and_issue(t + 1);
-            FA_TP(0);
-            scores(s1, stB);
-            FA_TP(1);
-        }
-        softmax_pv(t, stage, stA);
-        if (t + 1 >= ntiles) break;
-        if (t + 2 < ntiles) {
-            wait_and_issue(t + 2);
-            FA_TP(0);
-            scores(s2, stA);
-            FA_TP(1);
-        }
-        softmax_pv(t + 1, s1, stB);
-        stage = s2;
     }
-#ifdef FA_TIMELINE
-    if (lane == 0) {
-        float* o_ = fa_timeline_out + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + wid * 4;
-        for (int i = 0; i < 4; ++i) o_[i] = (float)fa_tl[i] / ntiles;
-    }
-#endif
     const float l_tot = xor_sum<32>(l_run);
     const int q = q0 + li;
     if (q < a.N) {
@@ -424,12 +368,17 @@ __global__ __launch_bounds__(ER_WG) void flash_attn_hh_kernel(FlashHArgs a) {
     }
 }
 
-// (Round 6 also measured an EIGHT-wave workgroup in which the two waves of a SIMD alternate a matrix phase and a softmax phase in
-// anti-phase, every phase closed by the workgroup barrier - commit 44ab76c, profiles/r06_flash_hh8_ab.log, r06_flash_hh8_timeline.log:
-// 72 us against 54.4 for the 2048 x 2048 self-attention.  A wave that has a pipe to itself still needs ~1400 cycles for its eight S +
-// eight P V MFMAs with their sixteen fragment reads, and ~1400 for its ~200 softmax instructions: one wave issues an instruction
-// every 4-7 cycles, so the phases are issue-bound, not pipe-bound, and the barrier per phase (440 cycles) comes on top.  s_setprio 1
-// around the score MFMAs: equal, 54.5 vs 54.8 us, r06_flash_hh_setprio_ab.log.)
+// Round 6 measured two restructurings of this kernel and kept neither (both live in commit 44ab76c with their probe,
+// scripts/probes/flash_hh_timeline_probe.hip; logs profiles/r06_flash_hh_*.log, r06_dit_trace_ab.log):
+//  * SOFTWARE PIPELINING - S^T of key tile t + 1 issued ahead of the softmax of tile t (five stages): bit-identical, 63.0 -> 54.4 us for
+//    the 2048 x 2048 self-attention when the kernel is replayed back to back on random data, but 51.2 -> 51.4 us IN SITU (rocprofv3
+//    medians of the two libraries on one box, the kernel between the DiT's GEMMs at a higher clock): no gain where it counts;
+//  * an EIGHT-wave workgroup whose two waves per SIMD alternate a matrix phase and a softmax phase in anti-phase behind the workgroup
+//    barrier: 72 us.  Its cycle stamps explain both results: a wave that has a pipe to itself still needs ~1400 cycles for its eight
+//    S + eight P V MFMAs with their sixteen fragment reads, and ~1400 for its ~200 softmax instructions - one wave issues an instruction
+//    every 4-7 cycles, so the loop is bound by the instruction issue of the two waves a SIMD holds, not by either pipe; s_setprio 1
+//    around the score MFMAs measured equal.  (Serial form, stamps per key tile and wave: wait + barrier 698 | S 333 | softmax 1205 |
+//    P V 595 cycles.)
 inline hipError_t launch_flash_attn_hh(const FlashHArgs& a, int H, int B, hipStream_t st) {
     dim3 grid((a.N + ER_NWAVES * FA_QW - 1) / (ER_NWAVES * FA_QW), H, B);
     hipLaunchKernelGGL(flash_attn_hh_kernel, grid, dim3(ER_WG), 0, st, a);

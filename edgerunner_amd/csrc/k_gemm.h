@@ -571,9 +571,12 @@ __device__ __forceinline__ void hh_epi_rows(const GemmArgs& g, const float* sw, 
             if (gn + 3 < g.N) bias.w = g.bias[gn + 3];
         }
         const RowBatch gb(mw, g.gate ? g.gate_rows : 0, WR), rb(mw, (g.resid && g.resid_mod > 0) ? g.resid_mod : 0, WR);
-        // The residual and gate operands of up to EIGHT passes are requested before the first of them is used (round 6): with the loads
-        // inside a 4-fold unrolled pass loop a wave had 4 x 1 KB in flight, 16-32 KB per CU - at ~2 us of loaded latency that is 2-4 TB/s.
-        // The gate row depends on the batch only: the wave's rows span at most two batches (RowBatch fast path), one float4 each.
+        // 32-row blocks (TM = 1: the N = 1024 residual products of the DiT): the residual operands of all eight passes are requested before
+        // the first is used (round 6) - with the loads inside a 4-fold unrolled pass loop a wave had 4 x 1 KB in flight, 16-32 KB per CU; in
+        // situ 32.8 -> 32.0 us mean over the four products (profiles/r06_dit_trace_ab.log).  64-row blocks (TM = 2: q/k/v, the 256 x 256 tile)
+        // keep the 4-fold unrolled loop: sixteen unrolled passes cost the q/k/v product 41.7 -> 47.5 us (same log; the round-3 lesson about
+        // unrolled per-element option code and the instruction cache).  The gate row depends on the batch only: the wave's rows span at
+        // most two batches (RowBatch fast path), one float4 each.
         constexpr int NPASS = WR / RPP / PARTS, CH = NPASS < 8 ? NPASS : 8;
         static_assert((WR / RPP) % PARTS == 0, "whole passes per part");
         const int t0 = part * NPASS;
@@ -587,23 +590,10 @@ __device__ __forceinline__ void hh_epi_rows(const GemmArgs& g, const float* sw, 
             gate1 = *reinterpret_cast<const f32x4*>(g.gate + (long long)gb1 * g.gate_bstride + gn);
         }
         const bool gate_pair = g.gate && vec && gb.fast;       // every row of the wave is in batch gb0 or gb1
-#pragma unroll
-        for (int c0 = 0; c0 < NPASS; c0 += CH) {
-            f32x4 rres[CH];
-            if (NPASS <= 8 && use_pre) {                       // (HhEpiPre holds at most eight passes: 32-row blocks only)
-#pragma unroll
-                for (int t = 0; t < CH; ++t) rres[t] = pre_->res[(c0 + t) & 7];
-            } else if (g.resid && vec) {
-#pragma unroll
-                for (int t = 0; t < CH; ++t) {
-                    const int gm = mw + rr0 + RPP * (t0 + c0 + t);
-                    const int rrow_ = g.resid_mod > 0 ? rb.inner(min(gm, g.M - 1)) : min(gm, g.M - 1);
-                    rres[t] = *reinterpret_cast<const f32x4*>(g.resid + (long long)rrow_ * g.ldr + gn);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                const int rr = rr0 + RPP * (t0 + c0 + t), gm = mw + rr;
+        if constexpr (NPASS > 8) {
+#pragma unroll 4
+            for (int t_ = 0; t_ < NPASS; ++t_) {
+                const int rr = rr0 + RPP * (t0 + t_), gm = mw + rr;
                 if (gm >= g.M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c4);
                 if (g.div != 0.f) { v.x = v.x / g.div; v.y = v.y / g.div; v.z = v.z / g.div; v.w = v.w / g.div; }
@@ -613,8 +603,8 @@ __device__ __forceinline__ void hh_epi_rows(const GemmArgs& g, const float* sw, 
                 const long long grow = g.gate ? (long long)gb.batch(gm) * g.gate_bstride + gn : 0;
                 if (vec) {
                     if (g.gate) v *= gate_pair ? (gb.batch(gm) == gb0 ? gate0 : gate1) : *reinterpret_cast<const f32x4*>(g.gate + grow);
-                    if (g.resid) v += rres[t];
-                    if (g.C) *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;     // null: only the fp16 copy is wanted
+                    if (g.resid) v += *reinterpret_cast<const f32x4*>(g.resid + rrow);
+                    if (g.C) *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;
                     if (g.c16) *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * g.ldc16 + gn) = (h16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 } else {
                     const float e[4] = {v.x, v.y, v.z, v.w};
@@ -626,6 +616,50 @@ __device__ __forceinline__ void hh_epi_rows(const GemmArgs& g, const float* sw, 
                         if (g.resid) w += g.resid[rrow + u];
                         if (g.C) g.C[(long long)gm * g.ldc + gn + u] = w;
                         if (g.c16) g.c16[(long long)gm * g.ldc16 + gn + u] = (_Float16)w;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c0 = 0; c0 < NPASS; c0 += CH) {
+                f32x4 rres[CH];
+                if (NPASS <= 8 && use_pre) {                       // (HhEpiPre holds at most eight passes: 32-row blocks only)
+#pragma unroll
+                    for (int t = 0; t < CH; ++t) rres[t] = pre_->res[(c0 + t) & 7];
+                } else if (g.resid && vec) {
+#pragma unroll
+                    for (int t = 0; t < CH; ++t) {
+                        const int gm = mw + rr0 + RPP * (t0 + c0 + t);
+                        const int rrow_ = g.resid_mod > 0 ? rb.inner(min(gm, g.M - 1)) : min(gm, g.M - 1);
+                        rres[t] = *reinterpret_cast<const f32x4*>(g.resid + (long long)rrow_ * g.ldr + gn);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int rr = rr0 + RPP * (t0 + c0 + t), gm = mw + rr;
+                    if (gm >= g.M) continue;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(sw + rr * WC + 4 * c4);
+                    if (g.div != 0.f) { v.x = v.x / g.div; v.y = v.y / g.div; v.z = v.z / g.div; v.w = v.w / g.div; }
+                    v += bias;
+                    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    const long long rrow = g.resid ? (long long)(g.resid_mod > 0 ? rb.inner(gm) : gm) * g.ldr + gn : 0;
+                    const long long grow = g.gate ? (long long)gb.batch(gm) * g.gate_bstride + gn : 0;
+                    if (vec) {
+                        if (g.gate) v *= gate_pair ? (gb.batch(gm) == gb0 ? gate0 : gate1) : *reinterpret_cast<const f32x4*>(g.gate + grow);
+                        if (g.resid) v += rres[t];
+                        if (g.C) *reinterpret_cast<f32x4*>(g.C + (long long)gm * g.ldc + gn) = v;     // null: only the fp16 copy is wanted
+                        if (g.c16) *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * g.ldc16 + gn) = (h16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (gn + u >= g.N) break;
+                            float w = e[u];
+                            if (g.gate) w *= g.gate[grow + u];
+                            if (g.resid) w += g.resid[rrow + u];
+                            if (g.C) g.C[(long long)gm * g.ldc + gn + u] = w;
+                            if (g.c16) g.c16[(long long)gm * g.ldc16 + gn + u] = (_Float16)w;
+                        }
                     }
                 }
             }

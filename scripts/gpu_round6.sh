@@ -17,6 +17,18 @@ d=json.load(open("gpurun_out/r06_dit_trace_by_shape.json"))
 for r in d["groups"][:14]: print(f"{r['kernel'][:60]:60s} grid {r['grid_threads']:>14s} wg {r['workgroup']:>4s} n {r['launches']:5d} mean {r['mean_us']:8.2f} med {r['median_us']:8.2f} min {r['min_us']:8.2f} us")
 PY
       ;;
+    dittrace_ab) # per-kernel in-situ comparison of two library builds on ONE box: LIBS="a.so b.so ..."
+      for L in ${LIBS:-edgerunner_amd/lib_r5_baseline.so edgerunner_amd/libedgerunner_hip.so}; do
+        T=$(basename $L .so); rm -rf /tmp/trace_$T
+        (cd /tmp && ER_LIB_PATH=$ROOT/$L timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$T -o r06 -- python $ROOT/scripts/bench_dit.py 16 6 fp16 > /dev/null 2> /dev/null)
+        python scripts/trace_by_shape.py $(find /tmp/trace_$T -name "*kernel_trace.csv" | head -1) gemm_hh flash_attn_hh ln_modulate > gpurun_out/r06_dit_trace_$T.json
+        echo "== $L"
+        python - <<PY
+import json
+d=json.load(open("gpurun_out/r06_dit_trace_$T.json"))
+for r in d["groups"][:6]: print(f"{r['kernel'][:56]:56s} grid {r['grid_threads']:>12s} n {r['launches']:5d} mean {r['mean_us']:8.2f} med {r['median_us']:8.2f} min {r['min_us']:8.2f} us")
+PY
+      done ;;
     gemm)    timeout 300 scripts/probes/gemm_hh_probe 2>&1 | tee gpurun_out/r06_gemm_hh_probe.log ;;
     gemmt)   timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -p no:cacheprovider --timeout 400 -x -k "gemm_hh" 2>&1 | filt | tail -8 | tee gpurun_out/r06_gemm_hh_tests.log ;;
     dit)     { timeout 900 python -m pytest tests/test_gpu_dit.py -q -m gpu -s -p no:cacheprovider --timeout 600 2>&1 | filt | tail -12
