@@ -19,6 +19,7 @@
 #include "k_outproj_merge.h"
 #include "k_flash_attn_f16s.h"
 #include "k_gemm.h"
+#include "k_gemm_stream.h"
 #include "k_gemv.h"
 #include "k_gemv_mfma.h"
 #include "k_head.h"

@@ -1078,8 +1078,24 @@ inline int gemm_hh_pick_tile(int M, int N) {
 }
 
 // A = fp16 [M][lda], B = fp16 weights [N][ldb] (both through g.A / g.B), K % 64 == 0
+// k_gemm_stream.h: the streamed form (loader + matrix waves, five-stage ring, persistent tile stream), bit-identical to the kernels above.
+// Rule (round 6, measured IN SITU, profiles/r06_dit_stream_in_situ*.log): the DEEP products whose 128 x 128 tiles fill the chip about once -
+// the DiT's feed-forward-out, 4096 x 1024 x 4096: guided forward 8.38 -> 8.13 ms - where its three k-tiles in flight hide the HBM latency
+// of operands that are cold in situ (24 layers of weights do not fit the Infinity Cache); on the K = 1024 products and on q/k/v it measured
+// slower in situ (8.22 / 8.34 ms), as in the replay probe, and so did its GEGLU form on the feed-forward-in (8.21 vs 7.94 ms,
+// r06_dit_stream_geglu_in_situ.log).  ER_GEMM_STREAM=0: never; =2: wherever it is legal (unit tests); read per launch.
+inline hipError_t launch_gemm_hh_stream(const GemmArgs& g, hipStream_t st, bool geglu);
+inline bool gemm_hh_use_stream(int M, int N, int K) {
+    const char* v = getenv("ER_GEMM_STREAM");
+    const int mode = v ? atoi(v) : 1;
+    if (mode == 0) return false;
+    if (mode == 2) return true;
+    const long long t = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    return K >= 2048 && t >= 128 && t <= 512;
+}
 inline hipError_t launch_gemm_hh(const GemmArgs& g, hipStream_t st, int force_tile = 0) {
     if (g.K % XBK != 0 || (g.lda & 7) || (g.ldb & 7)) return hipErrorInvalidValue;
+    if (!force_tile && gemm_hh_use_stream(g.M, g.N, g.K)) return launch_gemm_hh_stream(g, st, false);
     if (g.vt16 && ((g.M & 63) || (g.vt_rows & 63) || (g.vt_col0 & 127) || ((g.N - g.vt_col0) & 63) || (g.vt_ld & 7) || g.div != 0.f || g.relu ||
                    g.gate || g.resid))
         return hipErrorInvalidValue;

@@ -24,6 +24,9 @@
 //     the accumulator registers - 32-byte row segments per lane pair: 16 us against 10 us on the 4096 x 1024 residual shape,
 //     profiles/r06_gemm_stream_probe_v2.log; a second ran the row-wise epilogue on the four matrix waves only: 11-14 k cycles per tile,
 //     r06_gemm_stream_probe_v6.log.)
+// Where it runs: launch_gemm_hh's rule (k_gemm.h gemm_hh_use_stream) - the deep feed-forward-out product of the DiT, where it is faster
+// IN SITU; the probe builds (GS_TIMELINE, GS_ABL_*, ER_GEMM_PROBE_NO_EPILOGUE: scripts/probes/gemm_stream_probe.hip) are how its phases
+// were measured.
 // Same 128-byte row images, XOR swizzle, fragment reads and the same k order per accumulator element as gemm_hh_mfma_kernel; a product
 // a.w is the same number whichever operand slot it enters by: results are BIT-IDENTICAL to the 4-wave kernels (tests/test_gpu_kernels.py).
 #pragma once

@@ -1,13 +1,13 @@
 // Round 6: the streamed LDS-DMA GEMM (k_gemm_stream.h, loader + matrix waves, five-stage ring, persistent tile stream) against the
 // 4-wave and 256 x 256 kernels of k_gemm.h on the DiT shapes: throughput AND bit-equality of every epilogue form
 // (plain with bias / gate / residual / fp16 copy, V^T of a fused q/k/v projection, GEGLU), ragged shapes included.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I ../../edgerunner_amd/csrc -I . -o gemm_stream_probe gemm_stream_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I ../../edgerunner_amd/csrc -o gemm_stream_probe gemm_stream_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "k_gemm_stream.h"   // scripts/probes/k_gemm_stream.h (probe-only kernel)
+#include "k_gemm_stream.h"
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 using namespace er;
 
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
         const double flop = 2.0 * M * N * K;
         const GemmArgs g0 = args(0), g1 = args(1);
         const int ref_tile = s.mode == 2 ? 1 : 0;
-        auto run_ref = [&]() { return s.mode == 2 ? launch_gemm_hh_geglu(g0, st, ref_tile) : launch_gemm_hh(g0, st); };
+        auto run_ref = [&]() { return s.mode == 2 ? launch_gemm_hh_geglu(g0, st, ref_tile) : launch_gemm_hh(g0, st, gemm_hh_pick_tile(g0.M, g0.N)); };   // (force_tile: the k_gemm.h kernels only)
         #ifdef GS_TIMELINE
         static float* dbg_all = nullptr;
         if (!dbg_all) CHECK(hipMalloc(&dbg_all, 256 * 8 * 4));

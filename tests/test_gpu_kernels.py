@@ -388,6 +388,40 @@ def test_gemm_hh_qkv_writes_v_transposed(M, rows, heads, K, tile):
     assert torch.equal(vt, want), "V^T per head in MFMA key order"
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 4096), (4096, 1024, 1024), (3001, 4164, 192), (77, 200, 640), (129, 65, 128), (256, 384, 64), (2050, 1536, 6144)])
+def test_gemm_hh_streamed_form_is_bit_identical(M, N, K, monkeypatch):
+    """The streamed LDS-DMA GEMM (k_gemm_stream.h: loader + matrix waves, five-stage ring, persistent tile stream, eight-wave epilogue;
+    the DiT's feed-forward-out by launch_gemm_hh's rule) must give the bits of the 4-wave kernels on every shape - several tiles per
+    workgroup (3001 x 4164), fewer tiles than CUs, ragged M / N, one k-tile (K = 64) - with bias + residual + fp16 copy, and with ReLU."""
+    from edgerunner_amd import kernels as K_
+    a, w = rnd(M, K, seed=284), rnd(N, K, seed=285, scale=0.05)
+    bias, resid = rnd(N, seed=286), rnd(M, N, seed=287)
+    wh = w.half()
+    monkeypatch.setenv("ER_GEMM_STREAM", "0")
+    c0, h0 = K_.gemm_hh(a, wh, bias, resid, return_half=True)
+    r0 = K_.gemm_hh(a, wh, bias, None, relu=True)
+    monkeypatch.setenv("ER_GEMM_STREAM", "2")
+    c1, h1 = K_.gemm_hh(a, wh, bias, resid, return_half=True)
+    r1 = K_.gemm_hh(a, wh, bias, None, relu=True)
+    assert torch.equal(c1, c0) and torch.equal(h1, h0) and torch.equal(r1, r0), f"streamed form differs: max {float((c1 - c0).abs().max()):.3e}"
+    ref = a.half().double() @ wh.double().T + bias.double() + resid.double()
+    close(c1, ref, 1e-5 + 2e-7 * K, 1e-5, "streamed LDS-DMA fp16 gemm")
+
+
+@pytest.mark.parametrize("M,rows,heads,K", [(4096, 2048, 16, 1024), (384, 128, 4, 192)])
+def test_gemm_hh_streamed_form_qkv_v_transposed(M, rows, heads, K, monkeypatch):
+    """... and its V^T epilogue (the V third of a fused q/k/v projection leaves as V^T per head in fa_vt_pos order)."""
+    from edgerunner_amd import kernels as K_
+    N = 3 * heads * 64
+    a, w, bias = rnd(M, K, seed=291), rnd(N, K, seed=292, scale=0.05), rnd(N, seed=293)
+    wh = w.half()
+    monkeypatch.setenv("ER_GEMM_STREAM", "0")
+    qk0, vt0 = K_.gemm_hh_qkv(a, wh, bias, rows, force_tile=0)
+    monkeypatch.setenv("ER_GEMM_STREAM", "2")
+    qk1, vt1 = K_.gemm_hh_qkv(a, wh, bias, rows, force_tile=0)
+    assert torch.equal(qk1, qk0) and torch.equal(vt1, vt0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (2050, 4608, 1536), (2050, 1536, 6144), (514, 3072, 1024), (77, 200, 608)])
 def test_gemm_f16_split_activations(M, N, K):
     """Split-fp16 GEMM (fast-mode prefill): fp16 weights x (hi + lo)-split fp32 activations must equal the fp32-activation

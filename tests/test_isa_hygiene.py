@@ -197,3 +197,21 @@ def test_codegen_flags_are_accepted_and_take_effect(kernels, tmp_path):
     pre = kernels["__preload__"]
     hot = {n: v for n, v in pre.items() if re.search(r"attn_decode3_kernel|gemv_kernelI(f|DF16_)Li1E|outproj_merge_kernel", n)}
     assert hot and all(v >= 8 for v in hot.values()), ({n: v for n, v in hot.items() if v < 8}, "leading kernel arguments are not preloaded into SGPRs")
+
+
+def test_gemm_hh_stream_kernel_shape(kernels):
+    """k_gemm_stream.h: the loaders' LDS-DMA pieces are invisible to hipcc's wait bookkeeping, so the kernel must hold nothing that would
+    shift the hand-counted vmcnt waits - no scratch - and the matrix waves' k-step must be the tight form the timeline was measured on:
+    sixteen MFMAs fed by sixteen fragment reads with counted lgkmcnt waits (no lgkmcnt(0) drain between them) and ONE barrier."""
+    for n, b in select(kernels, r"gemm_hh_stream_kernelILi5ELi0E").items():
+        assert not [l for l in b if l.startswith("scratch_")], (n, "scratch access")
+        assert count(b, "global_load_lds_dwordx4") >= 16, n
+        for cnt in (16, 8, 0):
+            assert [l for l in b if l.startswith(f"s_waitcnt vmcnt({cnt})")], (n, f"no counted vmcnt({cnt}) wait")
+        mf = [i for i, l in enumerate(b) if l.startswith("v_mfma_f32_32x32x16_f16")]
+        assert len(mf) == 16, (n, len(mf))
+        # the k-step: from the barrier that closes the previous step to the one behind the last MFMA
+        start = max(i for i, l in enumerate(b[:mf[0]]) if l.startswith("s_barrier"))
+        loop = b[start:mf[-1] + 2]
+        assert count(loop, "ds_read_b128") == 16, (n, count(loop, "ds_read_b128"))
+        assert not [l for l in loop if l.startswith("s_waitcnt") and "lgkmcnt(0)" in l], (n, "a full LDS drain inside the k-step")
