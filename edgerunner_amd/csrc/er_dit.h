@@ -382,8 +382,8 @@ static int dit_cross_kv(er_dit_ctx* c, const float* cond, int B, int M, hipStrea
     return 0;
 }
 
-// DiT.forward body for B rows; timesteps in c->t_dev, cross K/V in c->kv2 (dit_cross_kv)
-static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float* out, hipStream_t st) {
+// DiT.forward body for B rows; their time embeddings temb [B][C] / tada [B][6 C] (dit_time_embed), cross K/V in c->kv2 (dit_cross_kv)
+static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float* out, const float* temb, const float* tada, hipStream_t st) {
     const er_dit_config& g = c->cfg;
     const int C = g.hidden_dim, N = g.latent_size, H = g.num_heads, D = C / H, LD = g.latent_dim;
     const int R = B * N;
@@ -428,10 +428,9 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     _Float16* qkv16 = hh ? reinterpret_cast<_Float16*>(c->qkv16.p) : nullptr;
     _Float16* vt16 = hh ? reinterpret_cast<_Float16*>(c->vt16.p) : nullptr;
     _Float16* q2_16 = hh ? reinterpret_cast<_Float16*>(c->q2_16.p) : nullptr;
-    ERCHK(dit_time_embed(c, B, st));
     {
         const long long ng = (long long)g.num_layers * 2 * B * C;
-        hipLaunchKernelGGL(adaln_gate_all_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, c->sst_ptrs, c->tada.p, c->gates.p,
+        hipLaunchKernelGGL(adaln_gate_all_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, c->sst_ptrs, tada, c->gates.p,
                            g.num_layers, B, C);
         HIPRET(hipGetLastError());
     }
@@ -443,7 +442,7 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
     for (int l = 0; l < g.num_layers; ++l) {
         const DitLayerW& L = c->layers[l];
         // x = norm1(x) * (1 + scale_msa) + shift_msa   (chunks 0 = shift, 1 = scale, 2 = gate)     dit.py:129-132
-        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 0, 1, st, x16));
+        HIPRET(dit_ln_mod(x, x, R, N, L.sst, tada, 6LL * C, C, 0, 1, st, x16));
         // x = x + gate_msa * attn1(x)                                               dit.py:133
         if (hh) {     // q, k leave the GEMM in fp16 only and V as V^T per head (its epilogue); K and V^T tiles then reach LDS by DMA
             HIPRET(dlin16(c, x16, C, L.qkv_w, L.qkv_b, nullptr, 3 * C, R, 3 * C, C, nullptr, 0, nullptr, 1, qkv16, st, vt16, N));
@@ -506,7 +505,7 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         if (hh) HIPRET(dlin16(c, att16, C, L.o2_w, L.o2_b, x, C, R, C, C, x, C, nullptr, 1, nullptr, st));
         else HIPRET(dlin(c, c->att.p, C, L.o2_w, L.o2_b, x, C, R, C, C, x, C, nullptr, 1, st));
         // x = norm2(x) * (1 + scale_mlp) + shift_mlp; x = x + gate_mlp * ff(x)     dit.py:137-139
-        HIPRET(dit_ln_mod(x, x, R, N, L.sst, c->tada.p, 6LL * C, C, 3, 4, st, x16));
+        HIPRET(dit_ln_mod(x, x, R, N, L.sst, tada, 6LL * C, C, 3, 4, st, x16));
         if (hh) {     // feed-forward in + GEGLU in one launch: the [R][8C] pre-activation never reaches HBM (dit.py FeedForward)
             GemmArgs fg = gemm_args_default();
             fg.A = reinterpret_cast<const float*>(x16); fg.B = reinterpret_cast<const float*>(L.ff0_p16); fg.bias = L.ff0_bp;
@@ -521,7 +520,7 @@ static int dit_forward_impl(er_dit_ctx* c, const float* xin, int B, int M, float
         else HIPRET(dlin(c, c->g.p, 4 * C, L.ff2_w, L.ff2_b, x, C, R, C, 4 * C, x, C, gate_mlp, N, st));
     }
     // shift, scale = scale_shift_table + t_emb; x = norm_out(x) * (1 + scale) + shift; proj_out     dit.py:190-194
-    HIPRET(dit_ln_mod(x, x, R, N, c->sst2, c->temb.p, (long long)C, 0, 0, 1, st, x16));
+    HIPRET(dit_ln_mod(x, x, R, N, c->sst2, temb, (long long)C, 0, 0, 1, st, x16));
     if (hh) HIPRET(dlin16(c, x16, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, nullptr, 0, nullptr, 1, nullptr, st));
     else HIPRET(dlin(c, x, C, c->proj_out_w, c->proj_out_b, out, LD, R, LD, C, nullptr, 0, nullptr, 1, st));
     return 0;
@@ -537,7 +536,8 @@ extern "C" int er_dit_forward(er_dit_ctx* c, const float* x, const float* cond, 
     HIPCHK(hipMemcpyAsync(c->t_dev.p, t_host, B * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     ERCHK(dit_cross_kv(c, cond, B, M, st));
-    return dit_forward_impl(c, x, B, M, out, st) < 0 ? -1 : ER_OK;
+    ERCHK(dit_time_embed(c, B, st));
+    return dit_forward_impl(c, x, B, M, out, c->temb.p, c->tada.p, st) < 0 ? -1 : ER_OK;
 }
 
 extern "C" int er_dit_sample(er_dit_ctx* c, const float* cond, int B, int M, float* latents, int steps, float guidance,
@@ -576,16 +576,25 @@ extern "C" int er_dit_sample(er_dit_ctx* c, const float* cond, int B, int M, flo
     ERCHK(dit_cross_kv(c, c->czero.p, 2 * B, M, st));
     ERCHK(ensure(c->xin, 2 * nlat));
     ERCHK(ensure(c->pred, 2 * nlat));
-    ERCHK(ensure(c->t_dev, (size_t)2 * B));
-    std::vector<float> th(2 * B);
-    for (int i = steps - 1 - init_step; i >= 0; --i) {     // scheduler.timesteps[init_step:]          models_dit.py:213
-        const int t = i * ratio + 1;
-        for (int b = 0; b < 2 * B; ++b) th[b] = (float)t;
-        HIPCHK(hipMemcpyAsync(c->t_dev.p, th.data(), 2 * B * sizeof(float), hipMemcpyHostToDevice, st));
+    // time embeddings of ALL the steps that will run, in one pass (round 6): the timesteps are known up front, so the three tiny Linears
+    // (2 B rows each, ~13 us per launch on the 64 x 64-tile GEMM), the two SiLUs and the sinusoid run once over nrun x 2 B rows instead
+    // of once per step, and the loop needs no host -> device copy and no stream synchronisation any more.  Rows are independent in every
+    // one of these kernels: the embeddings are bit-identical to the per-step ones.
+    const int nrun = steps - init_step, B2 = 2 * B;
+    ERCHK(ensure(c->t_dev, (size_t)nrun * B2));
+    {
+        std::vector<float> th((size_t)nrun * B2);
+        for (int k = 0; k < nrun; ++k)
+            for (int b = 0; b < B2; ++b) th[(size_t)k * B2 + b] = (float)((steps - 1 - init_step - k) * ratio + 1);   // scheduler.timesteps[init_step:]   models_dit.py:213
+        HIPCHK(hipMemcpyAsync(c->t_dev.p, th.data(), th.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));      // th goes out of scope
+    }
+    ERCHK(dit_time_embed(c, nrun * B2, st));
+    for (int k = 0; k < nrun; ++k) {
+        const int t = (steps - 1 - init_step - k) * ratio + 1;
         HIPCHK(hipMemcpyAsync(c->xin.p, latents, nlat * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(c->xin.p + nlat, latents, nlat * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));      // th is reused next iteration
-        if (dit_forward_impl(c, c->xin.p, 2 * B, M, c->pred.p, st) < 0) return -1;
+        if (dit_forward_impl(c, c->xin.p, B2, M, c->pred.p, c->temb.p + (size_t)k * B2 * C, c->tada.p + (size_t)k * B2 * 6 * C, st) < 0) return -1;
         const int prev = t - ratio;
         const float a_t = ac[t], a_p = prev >= 0 ? ac[prev] : ac[0];
         hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3((unsigned)((nlat + 255) / 256)), dim3(256), 0, st, latents, c->pred.p,
