@@ -36,7 +36,6 @@
 namespace er {
 
 constexpr int GS_BM = 128, GS_BN = 128, GS_THREADS = 512;
-constexpr int GS_NP = 8;                                     // LDS-DMA pieces per loader wave and k-tile (32 pieces of 8 rows / 4 loaders)
 constexpr int GS_STAGE_B = (GS_BM + GS_BN) * XBK * 2;        // bytes per ring stage: 128 A rows, then 128 B rows, 128 bytes each (32 KB)
 
 // Tile order inside the stream: bands of GS_GH tile rows, walked column by column.  The tiles an XCD's 32 workgroups hold at the same
@@ -51,6 +50,7 @@ __device__ __forceinline__ void gs_tile_coords(int lin, int ntx, int nty, int& t
     ty = r0 + in - tx * gh;
 }
 
+// (a loader wave issues EIGHT LDS-DMA pieces per k-tile - 32 pieces of 8 rows over 4 loaders: the vmcnt counts below are multiples of 8)
 template <int NT>
 __device__ __forceinline__ void gs_wait_tiles(int n) {      // at most n (<= NT) of this wave's k-tiles may still be in flight
     if constexpr (NT >= 3) { if (n >= 3) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; } }
