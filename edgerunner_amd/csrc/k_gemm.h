@@ -507,6 +507,19 @@ __device__ __forceinline__ bool hh_epi_vec(const GemmArgs& g, int gn) {
     return gn + 3 < g.N && (!g.C || !(g.ldc & 3)) && (!g.resid || !(g.ldr & 3)) && !(g.gate_bstride & 3) && (!g.c16 || !(g.ldc16 & 3));
 }
 
+// erf for the FUSED GEGLU epilogue of the fp16 front-end mode (round 6): Abramowitz & Stegun 7.1.26 - one reciprocal, one hardware exp2,
+// five FMAs - instead of OCML's erff (~42 instructions per element: the epilogue is VALU-bound on it, 64 calls per lane and 256 x 256
+// tile).  |error| <= 1.5e-7 for the formula (+ ~1 ulp each from v_rcp_f32 / v_exp_f32): three orders of magnitude below the fp16
+// rounding of the value it produces, so the fp16 output differs from the erff form only where a value sits on a rounding boundary
+// (tests/test_gpu_kernels.py::test_geglu_epilogue_erf_accuracy: for gate values >= -3 at most one fp16 ulp off the correctly rounded
+// gelu, on 0.26 % of a dense grid; below -3, where any float32 erf loses its digits in 1 + erf, absolute error < 3e-6).  Guided DiT forward
+// 7.60 -> 7.46 ms in situ (profiles/r06_dit_fast_erf_in_situ.log).  The exact (fp32) front-end keeps erff (k_rowops.h geglu_kernel).
+__device__ __forceinline__ float erf_as7126(float v) {
+    const float a = fabsf(v), t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+    const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    return copysignf(1.0f - p * __builtin_amdgcn_exp2f(-a * a * 1.4426950408889634f), v);
+}
+
 // accumulators -> the wave's (32 TM) x (32 TN) float slice of LDS, row-major
 template <int TM, int TN>
 __device__ __forceinline__ void hh_epi_stage(float* sw, const f32x16 (&acc)[TM][TN], int lane) {
@@ -680,10 +693,10 @@ __device__ __forceinline__ void hh_epi_rows(const GemmArgs& g, const float* sw, 
             f32x4 gt = *reinterpret_cast<const f32x4*>(sw + rr * WC + 32 + 4 * c);
             x += bx;
             gt += bg;
-            const float o0 = x.x * (gt.x * 0.5f * (1.0f + erff(gt.x * 0.70710678118654752440f)));
-            const float o1 = x.y * (gt.y * 0.5f * (1.0f + erff(gt.y * 0.70710678118654752440f)));
-            const float o2 = x.z * (gt.z * 0.5f * (1.0f + erff(gt.z * 0.70710678118654752440f)));
-            const float o3 = x.w * (gt.w * 0.5f * (1.0f + erff(gt.w * 0.70710678118654752440f)));
+            const float o0 = x.x * (gt.x * 0.5f * (1.0f + erf_as7126(gt.x * 0.70710678118654752440f)));
+            const float o1 = x.y * (gt.y * 0.5f * (1.0f + erf_as7126(gt.y * 0.70710678118654752440f)));
+            const float o2 = x.z * (gt.z * 0.5f * (1.0f + erf_as7126(gt.z * 0.70710678118654752440f)));
+            const float o3 = x.w * (gt.w * 0.5f * (1.0f + erf_as7126(gt.w * 0.70710678118654752440f)));
             *reinterpret_cast<h16x4*>(g.c16 + (long long)gm * F + jo) = (h16x4){(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
         }
     }

@@ -366,6 +366,38 @@ def test_gemm_hh_geglu_fused_epilogue(M, F, K):
         assert torch.equal(o, outs[1]), f"tile form {t} differs from the 128 x 128 form"
 
 
+def test_geglu_epilogue_erf_accuracy():
+    """The fused GEGLU epilogue evaluates erf by Abramowitz & Stegun 7.1.26 on the hardware reciprocal / exp2 (k_gemm.h erf_as7126)
+    instead of OCML's erff.  Direct check of the DEVICE function: a product whose gate pre-activation is a chosen grid value and whose
+    value part is exactly 1 (weights: identity rows for the gate, zero rows + bias 1 for the value), so the fp16 output IS gelu(grid).
+    Against float64, for gate values >= -3: never more than one fp16 ulp off the correctly rounded result, and off at all on < 0.5 % of
+    the grid (values near a rounding boundary; 0.26 % measured); below -3 (|gelu| < 5e-3): absolute error < 3e-6."""
+    from edgerunner_amd import kernels as K_
+    F, K = 64, 64
+    grid = torch.linspace(-6.0, 6.0, 4096 * 64, device=DEV).half().float().view(4096, 64)      # fp16-exact inputs: the GEMM rounds A to fp16
+    w = torch.zeros(2 * F, K, device=DEV)
+    w[F:] = torch.eye(F, device=DEV)                       # gate_j = a[:, j]
+    bias = torch.cat([torch.ones(F, device=DEV), torch.zeros(F, device=DEV)])
+    out = K_.gemm_hh_geglu(grid, w.half(), bias)           # (0 + 1) * gelu(a)
+    ref64 = torch.nn.functional.gelu(grid.double())
+    want = ref64.half()
+    # distance in fp16 ulps: compare the integer encodings of same-sign values
+    def enc(t):
+        i = t.view(torch.int16).to(torch.int32)
+        return torch.where(i < 0, -(i & 0x7fff), i)
+    d = (enc(out) - enc(want)).abs()
+    body = grid >= -3.0            # below -3 the result is 1 + erf ~ 1e-3 and smaller times x: ANY float32 erf (OCML's too) loses its digits to the
+                                   # cancellation in 1 + erf there; those outputs are < 5e-3 in magnitude and are held to an ABSOLUTE bound instead
+    assert int(d[body].max()) <= 1, f"fused GEGLU is {int(d[body].max())} fp16 ulps off the correctly rounded gelu for a gate value >= -3"
+    frac = float((d[body] > 0).float().mean())
+    err = (out.double() - ref64).abs()
+    print(f"GEGLU epilogue erf: {frac * 100:.3f} % of {int(body.sum())} grid values >= -3 differ from the correctly rounded fp16 gelu (by one ulp); "
+          f"max abs error over [-6, 6] {float(err.max()):.2e}, below -3 {float(err[~body].max()):.2e}")
+    assert frac < 5e-3
+    assert float(err[~body].max()) < 3e-6, "tail: absolute error of x * (1 + erf) / 2 for gate values below -3"
+    assert float((err / ref64.abs().clamp_min(1e-3)).max()) < 1.5e-3, "relative error beyond fp16 rounding"
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,rows,heads,K", [(4096, 2048, 16, 1024), (256, 64, 2, 64), (384, 128, 4, 192)])
 def test_gemm_hh_qkv_writes_v_transposed(M, rows, heads, K, tile):
