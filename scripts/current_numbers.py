@@ -30,7 +30,7 @@ def main():
         r = b2["roofline"]
         rows.append(f"| **configs[2]** full size, B = 32 sample (top-k 10), T = 16000, context to 18050 (`bench.py --config 2`) | **{b2['value']:.0f} tok/s** | streaming attention {r['bytes_per_launch'] / 1e9:.3f} GB / {r['avg_us_per_launch']:.0f} us = **{r['frac']:.3f}** | **{r['whole_step']['frac']:.3f}** | `r06_bench_config2.json` |")
     d = b["dit_front_end_fp16"]
-    rows.append(f"| **configs[4]** DiT front-end, fp16 matrix cores, 20 guided DDIM steps (`dit_front_end_fp16`) | **{d['ms_per_cfg_forward']:.2f} ms** per guided forward = {d['roofline']['achieved']:.0f} TFLOP/s = **{d['roofline']['frac']:.3f}** of 2.5 PFLOP/s (same-box A/Bs this round: 8.47 -> 8.39, 8.17 -> 7.97, 7.70 -> 7.64 ms) | MFMA-busy: `gemm_hh256_kernel` 0.34, `gemm_hh_stream_kernel` 0.29, `gemm_hh_mfma_kernel` 0.12-0.23, `flash_attn_hh_kernel` 0.22 (`r06_pmc_sq_dit.json`) | | `r06_bench.json`, `r06_dit_fp16_kernel_stats.csv`, `r06_dit_trace_by_shape.json`, `r06_dit_ab_final.log`, `r06_dit_stream_adopted.log`, `r06_dit_time_embed_ab.log` |")
+    rows.append(f"| **configs[4]** DiT front-end, fp16 matrix cores, 20 guided DDIM steps (`dit_front_end_fp16`) | **{d['ms_per_cfg_forward']:.2f} ms** per guided forward = {d['roofline']['achieved']:.0f} TFLOP/s = **{d['roofline']['frac']:.3f}** of 2.5 PFLOP/s (same-box A/Bs this round: 8.47 -> 8.39, 8.17 -> 7.97, 7.70 -> 7.64, 7.60 -> 7.46 ms) | MFMA-busy: `gemm_hh256_kernel` 0.34, `gemm_hh_stream_kernel` 0.29, `gemm_hh_mfma_kernel` 0.12-0.23, `flash_attn_hh_kernel` 0.22 (`r06_pmc_sq_dit.json`) | | `r06_bench.json`, `r06_dit_fp16_kernel_stats.csv`, `r06_dit_trace_by_shape.json`, `r06_dit_ab_final.log`, `r06_dit_stream_adopted.log`, `r06_dit_time_embed_ab.log`, `r06_dit_fast_erf_in_situ.log` |")
     cb = b["cpu_baseline"]
     rows.append(f"| `cpu_baseline` (oracle = reference modules bit for bit, this box's host cores) | {cb['value']:.2f} tok/s on {cb['cores']} threads (bounded sample) | | | `r06_bench.json` |")
     print("\n".join(rows))
